@@ -1,0 +1,48 @@
+/* Test-only helpers: comparators and input generators used by the known-answer tests.
+ * They re-create the INPUTS of the reference's example programs (never their code):
+ *  - kat_alphacmp: case-insensitive wide-char comparator, the behaviour of
+ *    examples/aho_corasick_generic_test.c:48-54.
+ *  - kat_rand_letters: the unseeded glibc rand() letter stream of generic_test.c:263-273.
+ *  - kat_read_novel: the fgetwc/iswalpha/towlower normalisation of generic_test.c:191-195.
+ */
+#define _GNU_SOURCE
+#include <locale.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <wchar.h>
+#include <wctype.h>
+
+int
+kat_alphacmp (const void *a, const void *b, const void *arg) {
+  (void)arg;
+  wint_t x = towlower (*(const wint_t *)a), y = towlower (*(const wint_t *)b);
+  return x > y ? 1 : (x < y ? -1 : 0);
+}
+
+/* next n letters 'a' + rand() % 26, continuing the process-wide rand() stream */
+void
+kat_rand_letters (unsigned char *out, size_t n) {
+  for (size_t i = 0; i < n; i++)
+    out[i] = (unsigned char)('a' + (size_t)rand () % 26);
+}
+
+void
+kat_srand (unsigned seed) {
+  srand (seed);
+}
+
+/* Reads a UTF-8 file wide-char by wide-char; non-alphabetic -> L' ', alphabetic -> lower case.
+ * Returns the number of wide chars written (<= cap), or -1 on error. */
+long
+kat_read_novel (const char *path, wchar_t *out, long cap) {
+  if (!setlocale (LC_ALL, "C.UTF-8") && !setlocale (LC_ALL, "C.utf8"))
+    return -1;
+  FILE *f = fopen (path, "r");
+  if (!f)
+    return -1;
+  long n = 0;
+  for (wint_t wc; (wc = fgetwc (f)) != WEOF && n < cap;)
+    out[n++] = iswalpha (wc) ? (wchar_t)towlower (wc) : L' ';
+  fclose (f);
+  return n;
+}
