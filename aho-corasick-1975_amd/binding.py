@@ -1,0 +1,420 @@
+"""ctypes bindings of libac75_amd.so (include/acm.h + include/acm_gpu.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBNAME = "libac75_amd.so"
+
+RECORD_DTYPE = np.dtype([("end_pos", "<u8"), ("length", "<u4"), ("keyword_id", "<u4")])
+
+ACM_GPU_OK = 0
+ACM_GPU_E_OVERFLOW = -4
+
+
+class ACMError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        msg = lib().acm_gpu_strerror(code).decode() if _lib is not None else str(code)
+        super().__init__("%s: %s (code %d)" % (what, msg, code))
+
+
+def library_path():
+    return os.path.join(_HERE, _LIBNAME)
+
+
+def build_native(force=False):
+    """Compile libac75_amd.so in-tree with the committed Makefile (hipcc --offload-arch=gfx950;
+    cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.run(["make", "-s", "-C", csrc, "clean"], check=True)
+    subprocess.run(["make", "-s", "-C", csrc], check=True)
+    return library_path()
+
+
+class MatchHolder(C.Structure):
+    _fields_ = [("letters", C.POINTER(C.c_void_p)), ("length", C.c_size_t), ("value", C.c_void_p)]
+
+
+class FlatInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("sym_bytes", "n_states", "n_keywords", "n_edges", "lmax", "max_outputs",
+                                          "alpha_lo", "alpha_span", "width")]
+
+
+class FlatView(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_uint32)) for n in ("row_ptr", "edge_sym", "edge_next", "fail", "depth", "nb_outputs",
+                                                     "term_kw", "out_link", "depth_start", "kw_state")]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("device", C.c_int)] + [(n, C.c_uint32) for n in (
+        "kernel", "entry_bytes", "width", "dense_rows", "lds_rows", "lds_bytes", "block_threads", "grid_blocks",
+        "chunk_bytes", "streams")] + [("table_bytes", C.c_uint64)]
+
+
+_lib = None
+
+# every symbol include/acm.h and include/acm_gpu.h declare
+EXPORTS = [
+    "ACM_CMP_DEFAULT", "ACM_INCREMENTAL_STRING_MATCHING", "acm_create", "acm_initiate",
+    "acm_insert_letter_of_keyword", "acm_insert_end_of_keyword", "acm_match", "acm_matcher_init", "acm_get_match",
+    "acm_matcher_release", "acm_nb_keywords", "acm_foreach_keyword", "acm_release", "acm_print",
+    "acm_gpu_strerror", "acm_gpu_device_count", "acm_flatten", "acm_flat_release", "acm_flat_info", "acm_flat_view",
+    "acm_flat_dense_rows", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_destroy",
+    "acm_gpu_plan_info", "acm_gpu_scan_device", "acm_gpu_count_device", "acm_gpu_sort_tmp_bytes",
+    "acm_gpu_sort_records_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
+    "acm_gpu_plan_timing_read", "acm_gpu_synth_text",
+]
+
+
+def lib():
+    """Loads the native library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or make -C aho-corasick-1975_amd/csrc) first" % path)
+    L = C.CDLL(path)
+    vp, sz, u64, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int
+    L.acm_create.restype = vp
+    L.acm_create.argtypes = [vp, vp, vp]
+    L.acm_initiate.restype = vp
+    L.acm_initiate.argtypes = [vp]
+    L.acm_insert_letter_of_keyword.restype = None
+    L.acm_insert_letter_of_keyword.argtypes = [C.POINTER(vp), vp]
+    L.acm_insert_end_of_keyword.restype = vp
+    L.acm_insert_end_of_keyword.argtypes = [C.POINTER(vp), vp, vp]
+    L.acm_match.restype = sz
+    L.acm_match.argtypes = [C.POINTER(vp), vp]
+    L.acm_matcher_init.restype = None
+    L.acm_matcher_init.argtypes = [C.POINTER(MatchHolder)]
+    L.acm_get_match.restype = None
+    L.acm_get_match.argtypes = [vp, sz, C.POINTER(MatchHolder)]
+    L.acm_matcher_release.restype = None
+    L.acm_matcher_release.argtypes = [C.POINTER(MatchHolder)]
+    L.acm_nb_keywords.restype = sz
+    L.acm_nb_keywords.argtypes = [vp]
+    L.acm_foreach_keyword.restype = None
+    L.acm_foreach_keyword.argtypes = [vp, vp]
+    L.acm_release.restype = None
+    L.acm_release.argtypes = [vp]
+    L.acm_print.restype = None
+    L.acm_print.argtypes = [vp, vp, vp]
+    L.acm_gpu_strerror.restype = C.c_char_p
+    L.acm_gpu_strerror.argtypes = [i32]
+    L.acm_gpu_device_count.restype = i32
+    L.acm_flatten.restype = i32
+    L.acm_flatten.argtypes = [vp, C.POINTER(vp)]
+    L.acm_flat_release.restype = None
+    L.acm_flat_release.argtypes = [vp]
+    L.acm_flat_info.restype = None
+    L.acm_flat_info.argtypes = [vp, C.POINTER(FlatInfo)]
+    L.acm_flat_view.restype = None
+    L.acm_flat_view.argtypes = [vp, C.POINTER(FlatView)]
+    L.acm_flat_dense_rows.restype = i32
+    L.acm_flat_dense_rows.argtypes = [vp, u32, u32, vp]
+    L.acm_gpu_plan_create.restype = i32
+    L.acm_gpu_plan_create.argtypes = [vp, i32, C.POINTER(vp)]
+    L.acm_gpu_plan_create_flat.restype = i32
+    L.acm_gpu_plan_create_flat.argtypes = [vp, i32, C.POINTER(vp)]
+    L.acm_gpu_plan_destroy.restype = None
+    L.acm_gpu_plan_destroy.argtypes = [vp]
+    L.acm_gpu_plan_info.restype = None
+    L.acm_gpu_plan_info.argtypes = [vp, C.POINTER(PlanInfo)]
+    L.acm_gpu_scan_device.restype = i32
+    L.acm_gpu_scan_device.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, vp]
+    L.acm_gpu_count_device.restype = i32
+    L.acm_gpu_count_device.argtypes = [vp, vp, u64, u64, vp, vp]
+    L.acm_gpu_sort_tmp_bytes.restype = sz
+    L.acm_gpu_sort_tmp_bytes.argtypes = [u64]
+    L.acm_gpu_sort_records_device.restype = i32
+    L.acm_gpu_sort_records_device.argtypes = [vp, vp, u64, vp, sz, vp]
+    L.acm_gpu_scan_host.restype = i32
+    L.acm_gpu_scan_host.argtypes = [vp, vp, u64, u64, u64, vp, u64, C.POINTER(u64)]
+    L.acm_scan.restype = i32
+    L.acm_scan.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    L.acm_gpu_plan_timing.restype = i32
+    L.acm_gpu_plan_timing.argtypes = [vp, i32]
+    L.acm_gpu_plan_timing_read.restype = i32
+    L.acm_gpu_plan_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.acm_gpu_synth_text.restype = i32
+    L.acm_gpu_synth_text.argtypes = [i32, vp, u64, u64, u32, u32, vp, vp, u32, vp]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != ACM_GPU_OK:
+        raise ACMError(rc, what)
+
+
+_SYM_DTYPE = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}
+
+
+class FlatTables:
+    """Host snapshot of the machine's flattened goto/failure/output tables (acm_flatten)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        L = lib()
+        info = FlatInfo()
+        L.acm_flat_info(handle, C.byref(info))
+        self.info = info
+        v = FlatView()
+        L.acm_flat_view(handle, C.byref(v))
+        n, ne = info.n_states, info.n_edges
+
+        def arr(p, cnt):
+            return np.ctypeslib.as_array(p, shape=(cnt,)).copy() if cnt else np.zeros(0, np.uint32)
+        self.row_ptr = arr(v.row_ptr, n + 1)
+        self.edge_sym = arr(v.edge_sym, ne)
+        self.edge_next = arr(v.edge_next, ne)
+        self.fail = arr(v.fail, n)
+        self.depth = arr(v.depth, n)
+        self.nb_outputs = arr(v.nb_outputs, n)
+        self.term_kw = arr(v.term_kw, n)
+        self.out_link = arr(v.out_link, n)
+        self.depth_start = arr(v.depth_start, info.lmax + 2)
+        self.kw_state = arr(v.kw_state, info.n_keywords)
+
+    def dense_rows(self, n_rows=None, entry_bytes=None):
+        info = self.info
+        n_rows = info.n_states if n_rows is None else n_rows
+        entry_bytes = (2 if info.n_states <= 32768 else 4) if entry_bytes is None else entry_bytes
+        out = np.zeros(n_rows * info.width, dtype=np.uint16 if entry_bytes == 2 else np.uint32)
+        _check(lib().acm_flat_dense_rows(self._h, n_rows, entry_bytes, out.ctypes.data), "acm_flat_dense_rows")
+        return out.reshape(n_rows, info.width)
+
+    def close(self):
+        if self._h:
+            lib().acm_flat_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Machine:
+    """An ACMachine over fixed-size symbols compared with ACM_CMP_DEFAULT (reference
+    aho_corasick.h:35,45), i.e. what `acm_create (ACM_CMP_DEFAULT, &(size_t){ sym_size }, 0)` returns.
+    Other comparators are available through the raw C API (lib())."""
+
+    def __init__(self, sym_size=1):
+        L = lib()
+        self.L = L
+        self.sym_size = sym_size
+        self._arg = C.c_size_t(sym_size)
+        cmp_default = C.c_void_p.in_dll(L, "ACM_CMP_DEFAULT")
+        self.handle = L.acm_create(cmp_default, C.cast(C.pointer(self._arg), C.c_void_p), None)
+        self._keep = []  # letters must outlive the machine (reference aho_corasick.h:39-43)
+        self.lmax = 0
+
+    def close(self):
+        if self.handle:
+            self.L.acm_release(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _symbols(self, x):
+        if isinstance(x, (bytes, bytearray)):
+            x = np.frombuffer(bytes(x), dtype=np.uint8)
+        return np.ascontiguousarray(x, dtype=_SYM_DTYPE[self.sym_size])
+
+    def add_keyword(self, symbols, value=None):
+        """acm_insert_letter_of_keyword per symbol then acm_insert_end_of_keyword.  Returns the
+        previous value pointer (None when the keyword had no value yet)."""
+        arr = self._symbols(symbols)
+        assert arr.size > 0
+        self._keep.append(arr)
+        L = self.L
+        cur = C.c_void_p(L.acm_initiate(self.handle))
+        base = arr.ctypes.data
+        for i in range(arr.size):
+            L.acm_insert_letter_of_keyword(C.byref(cur), base + i * self.sym_size)
+        self.lmax = max(self.lmax, int(arr.size))
+        return L.acm_insert_end_of_keyword(C.byref(cur), value, None)
+
+    def add_keywords_packed(self, data, offsets):
+        data = self._symbols(data)
+        self._keep.append(data)
+        L = self.L
+        base, ss = data.ctypes.data, self.sym_size
+        ins, end, init = L.acm_insert_letter_of_keyword, L.acm_insert_end_of_keyword, L.acm_initiate
+        for k in range(len(offsets) - 1):
+            cur = C.c_void_p(init(self.handle))
+            ref = C.byref(cur)
+            for i in range(int(offsets[k]), int(offsets[k + 1])):
+                ins(ref, base + i * ss)
+            end(ref, None, None)
+            self.lmax = max(self.lmax, int(offsets[k + 1] - offsets[k]))
+
+    @property
+    def nb_keywords(self):
+        return int(self.L.acm_nb_keywords(self.handle))
+
+    def match_loop(self, text):
+        """The reference's caller loop through the per-symbol host API (examples/test.c:17-23):
+        returns records (end_pos, length) and, per record, the matched spelling.  Slow (ctypes
+        call per symbol): API-parity tests only."""
+        t = self._symbols(text)
+        L = self.L
+        cur = C.c_void_p(L.acm_initiate(self.handle))
+        h = MatchHolder()
+        L.acm_matcher_init(C.byref(h))
+        out = []
+        base = t.ctypes.data
+        ptr_t = C.POINTER({1: C.c_uint8, 2: C.c_uint16, 4: C.c_uint32, 8: C.c_uint64}[self.sym_size])
+        for i in range(t.size):
+            nb = L.acm_match(C.byref(cur), base + i * self.sym_size)
+            for j in range(nb):
+                L.acm_get_match(cur, j, C.byref(h))
+                word = tuple(C.cast(h.letters[k], ptr_t)[0] for k in range(h.length))
+                out.append((i, int(h.length), word, h.value))
+        L.acm_matcher_release(C.byref(h))
+        return out
+
+    def flatten(self):
+        h = C.c_void_p()
+        _check(self.L.acm_flatten(self.handle, C.byref(h)), "acm_flatten")
+        return FlatTables(h)
+
+    def plan(self, device=0):
+        h = C.c_void_p()
+        _check(self.L.acm_gpu_plan_create(self.handle, device, C.byref(h)), "acm_gpu_plan_create")
+        return Plan(h, self.sym_size)
+
+    def scan_host(self, text, capacity=None):
+        """acm_scan(): host buffers in, canonical records out (GPU inside)."""
+        t = self._symbols(text)
+        cap = int(capacity) if capacity is not None else max(1024, t.size // 64)
+        while True:
+            out = np.zeros(cap, dtype=RECORD_DTYPE)
+            n = C.c_uint64(0)
+            rc = self.L.acm_scan(self.handle, t.ctypes.data, t.size, out.ctypes.data, cap, C.byref(n))
+            if rc == ACM_GPU_E_OVERFLOW and capacity is None:
+                cap = int(n.value)
+                continue
+            _check(rc, "acm_scan")
+            return out[:n.value]
+
+
+class Plan:
+    """Device-resident flattened automaton (ACMPlan).  Scans take torch CUDA tensors (device
+    memory and streams are torch's; the kernels are this library's)."""
+
+    def __init__(self, handle, sym_size):
+        self.h = handle
+        self.sym_size = sym_size
+        info = PlanInfo()
+        lib().acm_gpu_plan_info(handle, C.byref(info))
+        self.info = info
+
+    def close(self):
+        if self.h:
+            lib().acm_gpu_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def describe(self):
+        i = self.info
+        return {n: getattr(i, n) for n, _ in PlanInfo._fields_}
+
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def scan(self, text, n_symbols=None, emit_from=0, pos_base=0, capacity=None, records=None, count=None):
+        """Unsorted scan of a device tensor (uint8 storage of n_symbols * sym_size bytes, or a
+        tensor of the symbol dtype).  Returns (records u64[capacity, 2] tensor, count tensor).
+        Asynchronous on the current stream."""
+        import torch
+        assert text.is_cuda and text.is_contiguous()
+        if n_symbols is None:
+            n_symbols = text.numel() * text.element_size() // self.sym_size
+        if records is None:
+            cap = int(capacity) if capacity is not None else max(4096, n_symbols // 256)
+            records = torch.empty((cap, 2), dtype=torch.int64, device=text.device)
+        if count is None:
+            count = torch.zeros(1, dtype=torch.int64, device=text.device)
+        _check(lib().acm_gpu_scan_device(self.h, text.data_ptr(), n_symbols, emit_from, pos_base, records.data_ptr(),
+                                         records.shape[0], count.data_ptr(), self._stream()), "acm_gpu_scan_device")
+        return records, count
+
+    def count(self, text, n_symbols=None, emit_from=0, count=None):
+        import torch
+        if n_symbols is None:
+            n_symbols = text.numel() * text.element_size() // self.sym_size
+        if count is None:
+            count = torch.zeros(1, dtype=torch.int64, device=text.device)
+        _check(lib().acm_gpu_count_device(self.h, text.data_ptr(), n_symbols, emit_from, count.data_ptr(),
+                                          self._stream()), "acm_gpu_count_device")
+        return count
+
+    def sort(self, records, n):
+        """Canonical order (end_pos asc, length desc) of the first n records, in place."""
+        import torch
+        if n <= 1:
+            return records
+        tb = lib().acm_gpu_sort_tmp_bytes(n)
+        tmp = torch.empty(tb, dtype=torch.uint8, device=records.device)
+        _check(lib().acm_gpu_sort_records_device(self.h, records.data_ptr(), n, tmp.data_ptr(), tb, self._stream()),
+               "acm_gpu_sort_records_device")
+        return records
+
+    def scan_sorted(self, text, n_symbols=None, emit_from=0, pos_base=0, capacity=None):
+        """Scan + canonical sort; grows the record buffer when it overflowed (nothing is dropped).
+        Returns a numpy structured array (RECORD_DTYPE)."""
+        import torch
+        cap = capacity
+        while True:
+            rec, cnt = self.scan(text, n_symbols, emit_from, pos_base, cap)
+            n = int(cnt.item())
+            if n > rec.shape[0]:
+                cap = n
+                continue
+            self.sort(rec, n)
+            torch.cuda.synchronize(text.device)
+            return np.frombuffer(rec[:n].cpu().numpy().tobytes(), dtype=RECORD_DTYPE).copy()
+
+    def scan_host(self, text, emit_from=0, pos_base=0, capacity=None):
+        """acm_gpu_scan_host(): numpy in, numpy out, through the C ABI only (no torch)."""
+        t = np.ascontiguousarray(text)
+        n_sym = t.size * t.itemsize // self.sym_size
+        cap = int(capacity) if capacity is not None else max(1024, n_sym // 64)
+        while True:
+            out = np.zeros(cap, dtype=RECORD_DTYPE)
+            n = C.c_uint64(0)
+            rc = lib().acm_gpu_scan_host(self.h, t.ctypes.data, n_sym, emit_from, pos_base, out.ctypes.data, cap,
+                                         C.byref(n))
+            if rc == ACM_GPU_E_OVERFLOW and capacity is None:
+                cap = int(n.value)
+                continue
+            _check(rc, "acm_gpu_scan_host")
+            return out[:n.value]
+
+    def timing(self, enable=True):
+        _check(lib().acm_gpu_plan_timing(self.h, 1 if enable else 0), "acm_gpu_plan_timing")
+
+    def timing_read(self):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _check(lib().acm_gpu_plan_timing_read(self.h, C.byref(ms), C.byref(n)), "acm_gpu_plan_timing_read")
+        return ms.value, int(n.value)

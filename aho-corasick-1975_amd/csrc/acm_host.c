@@ -1,0 +1,469 @@
+/*
+ * acm_host.c -- host side of the drop-in: the acm_* API of include/acm.h.
+ *
+ * Own design, same observable behaviour as /root/reference/aho_corasick.c:
+ *   - states live in slab arenas (stable addresses: an ACState* is the caller's cursor);
+ *   - a state's goto edges are a comparator-ordered vector of child pointers (each child carries
+ *     the letter of its incoming edge), searched by bisection -- the role minimaps' ordered map
+ *     plays at aho_corasick.c:175,299;
+ *   - failure links, output counts and the inverse failure sets are kept exact after EVERY
+ *     inserted symbol (Meyer 1985, the reference's default build, aho_corasick.c:194-267,318-363),
+ *     so matching and insertion interleave freely (generic_test.c:198-229);
+ *   - every terminal state also records its first-insertion rank (keyword_id of acm_gpu.h) and
+ *     every state its depth, which the flattener (acm_flat.c) ships to the GPU.
+ */
+#define _GNU_SOURCE
+#include "acm_internal.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <threads.h>
+
+/* reference error convention, aho_corasick.c:24-36: message on stderr, the calling THREAD exits. */
+#define ACM_REQUIRE(cond, msg)                                                                      \
+  do {                                                                                              \
+    if (!(cond)) {                                                                                  \
+      fflush (stdout);                                                                              \
+      fprintf (stderr, "FATAL ERROR: A prerequisite is not fulfilled in function %s.\n", __func__); \
+      fprintf (stderr, "             %s\n", (msg)[0] ? (msg) : "The condition (" #cond ") is false."); \
+      thrd_exit (EXIT_FAILURE);                                                                     \
+    }                                                                                               \
+  } while (0)
+
+#define SLAB_STATES 4096
+
+struct slab {
+  struct slab *next;
+  uint32_t used;
+  struct _ac_state states[SLAB_STATES];
+};
+
+struct _ac_machine {
+  struct _ac_state *root;
+  size_t nb_keywords;
+  uint32_t nb_states;
+  uint64_t generation;
+  CMP_TYPE cmp;
+  void *cmp_arg;
+  DESTROY_TYPE letter_dtor;
+  struct slab *slabs;
+  mtx_t lock;
+  void *plan; /* cached device plan, see acm_gpu.hip */
+};
+
+void (*acm_internal_plan_dropper) (void *plan) = 0;
+
+/* ------------------------------------------------------------------ default comparator */
+static int
+cmp_bytes (const void *a, const void *b, const void *arg) { /* reference :134-138 */
+  return memcmp (a, b, *(const size_t *)arg);
+}
+const CMP_TYPE ACM_CMP_DEFAULT = cmp_bytes;
+const int ACM_INCREMENTAL_STRING_MATCHING = 1; /* reference :596-597 (default build) */
+
+/* ------------------------------------------------------------------ internal accessors */
+uint64_t
+acm_internal_generation (const ACMachine *m) {
+  return m->generation;
+}
+ACState *
+acm_internal_root (const ACMachine *m) {
+  return m->root;
+}
+uint32_t
+acm_internal_nb_states (const ACMachine *m) {
+  return m->nb_states;
+}
+int
+acm_internal_symbol_bytes (const ACMachine *m, uint32_t *sym_bytes) {
+  if (m->cmp != ACM_CMP_DEFAULT || !m->cmp_arg)
+    return ACM_GPU_E_INELIGIBLE;
+  size_t sz = *(const size_t *)m->cmp_arg;
+  if (sz != 1 && sz != 2 && sz != 4)
+    return ACM_GPU_E_INELIGIBLE;
+  *sym_bytes = (uint32_t)sz;
+  return ACM_GPU_OK;
+}
+void
+acm_internal_lock (ACMachine *m) {
+  ACM_REQUIRE (mtx_lock (&m->lock) == thrd_success, "");
+}
+void
+acm_internal_unlock (ACMachine *m) {
+  ACM_REQUIRE (mtx_unlock (&m->lock) == thrd_success, "");
+}
+void **
+acm_internal_plan_slot (ACMachine *m) {
+  return &m->plan;
+}
+
+/* ------------------------------------------------------------------ states */
+static struct _ac_state *
+state_alloc (ACMachine *m) {
+  struct slab *sl = m->slabs;
+  if (!sl || sl->used == SLAB_STATES) {
+    sl = malloc (sizeof *sl);
+    ACM_REQUIRE (sl, "Out of memory.");
+    sl->next = m->slabs;
+    sl->used = 0;
+    m->slabs = sl;
+  }
+  struct _ac_state *s = &sl->states[sl->used++];
+  memset (s, 0, sizeof *s);
+  s->machine = m;
+  s->id = m->nb_states++;
+  s->rank = UINT32_MAX;
+  return s;
+}
+
+/* bisection among the children of s; *at = where a missing letter would be inserted */
+static inline struct _ac_state *
+child_find (const struct _ac_state *s, const void *letter, uint32_t *at) {
+  const ACMachine *m = s->machine;
+  uint32_t lo = 0, hi = s->nkids;
+  while (lo < hi) {
+    uint32_t mid = lo + (hi - lo) / 2;
+    struct _ac_state *k = s->kids[mid];
+    int c = m->cmp (letter, k->letter, m->cmp_arg);
+    if (c == 0)
+      return k;
+    if (c < 0)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  if (at)
+    *at = lo;
+  return 0;
+}
+
+/* delta(s, letter) of the automaton WITHOUT root self-loops: goto if defined, else down the
+ * failure chain; a miss at the root stays there (reference state_goto, :167-192). */
+static inline const struct _ac_state *
+automaton_step (const struct _ac_state *s, const void *letter) {
+  for (;;) {
+    const struct _ac_state *k = child_find (s, letter, 0);
+    if (k)
+      return k;
+    if (!s->fail) /* only the root has no failure link */
+      return s;
+    s = s->fail;
+  }
+}
+
+static void
+inv_add (struct _ac_state *owner, struct _ac_state *x) {
+  if (owner->ninv == owner->capinv) {
+    owner->capinv = owner->capinv ? 2 * owner->capinv : 4;
+    owner->inv = realloc (owner->inv, owner->capinv * sizeof *owner->inv);
+    ACM_REQUIRE (owner->inv, "Out of memory.");
+  }
+  x->inv_slot = owner->ninv;
+  owner->inv[owner->ninv++] = x;
+}
+
+static void
+inv_del (struct _ac_state *owner, struct _ac_state *x) {
+  struct _ac_state *last = owner->inv[--owner->ninv];
+  owner->inv[x->inv_slot] = last;
+  last->inv_slot = x->inv_slot;
+}
+
+/* explicit stack for walks over the failure tree (depth can reach the number of states) */
+struct walk {
+  struct _ac_state **v;
+  size_t n, cap;
+};
+static inline void
+walk_push (struct walk *w, struct _ac_state *s) {
+  if (w->n == w->cap) {
+    w->cap = w->cap ? 2 * w->cap : 64;
+    w->v = realloc (w->v, w->cap * sizeof *w->v);
+    ACM_REQUIRE (w->v, "Out of memory.");
+  }
+  w->v[w->n++] = s;
+}
+
+/* New leaf `leaf` = child of n on letter c has just been linked into the goto tree.
+ * Failure maintenance (Meyer 1985; reference :194-208, :211-239, :253-265):
+ *   f(leaf) = delta(f(n), c), or the root when n is the root;
+ *   every existing node x.c whose longest proper suffix in the trie has just become `leaf` is
+ *   re-pointed: those are the c-children of the nodes x met by a walk down the failure tree from
+ *   n that stops at the first node owning a c-child on each branch.
+ * The walk runs on the tree as it was BEFORE any re-pointing (targets are collected first), so
+ * it does not depend on container mutation order. */
+static void
+link_failure_of_new_leaf (struct _ac_state *n, struct _ac_state *leaf) {
+  if (n->fail)
+    leaf->fail = (struct _ac_state *)automaton_step (n->fail, leaf->letter);
+  else
+    leaf->fail = n; /* depth-1 states fail to the root */
+  leaf->nb_outputs = leaf->fail->nb_outputs; /* leaf is not (yet) a keyword end */
+
+  if (n->ninv) {
+    struct walk todo = { 0 }, hits = { 0 };
+    for (uint32_t i = 0; i < n->ninv; i++)
+      walk_push (&todo, n->inv[i]);
+    while (todo.n) {
+      struct _ac_state *x = todo.v[--todo.n];
+      struct _ac_state *xc = child_find (x, leaf->letter, 0);
+      if (xc)
+        walk_push (&hits, xc);
+      else
+        for (uint32_t i = 0; i < x->ninv; i++)
+          walk_push (&todo, x->inv[i]);
+    }
+    for (size_t i = 0; i < hits.n; i++) {
+      struct _ac_state *xc = hits.v[i];
+      /* old f(xc) == f(leaf): both are the longest suffix shorter than leaf, so nb_outputs(xc)
+       * is unchanged by the re-pointing. */
+      inv_del (xc->fail, xc);
+      xc->fail = leaf;
+      inv_add (leaf, xc);
+    }
+    free (todo.v);
+    free (hits.v);
+  }
+  inv_add (leaf->fail, leaf);
+}
+
+/* ------------------------------------------------------------------ public API */
+ACMachine *
+acm_create (CMP_TYPE cmp, void *cmp_arg, DESTROY_TYPE dtor) {
+  ACM_REQUIRE (cmp, "A comparison function should be provided.");
+  ACMachine *m = calloc (1, sizeof *m);
+  ACM_REQUIRE (m, "Out of memory.");
+  m->cmp = cmp;
+  m->cmp_arg = cmp_arg;
+  m->letter_dtor = dtor;
+  m->root = state_alloc (m);
+  ACM_REQUIRE (mtx_init (&m->lock, mtx_plain) == thrd_success, "Out of memory.");
+  return m;
+}
+
+void
+acm_release (ACMachine *machine) {
+  ACM_REQUIRE (machine, "Invalid null machine.");
+  if (machine->plan && acm_internal_plan_dropper)
+    acm_internal_plan_dropper (machine->plan);
+  for (struct slab *sl = machine->slabs; sl;) {
+    for (uint32_t i = 0; i < sl->used; i++) {
+      struct _ac_state *s = &sl->states[i];
+      if (s->parent && machine->letter_dtor) /* stored letters, reference :111-112 */
+        machine->letter_dtor (s->letter);
+      if (s->value_dtor) /* reference :124-125 */
+        s->value_dtor (s->value);
+      free (s->kids);
+      free (s->inv);
+    }
+    struct slab *next = sl->next;
+    free (sl);
+    sl = next;
+  }
+  mtx_destroy (&machine->lock);
+  free (machine);
+}
+
+ACState *
+acm_initiate (ACMachine *machine) {
+  ACM_REQUIRE (machine, "Invalid null machine.");
+  return machine->root;
+}
+
+void
+acm_insert_letter_of_keyword (ACState **state, void *letter) {
+  ACM_REQUIRE (state && *state && letter, "Invalid null state or letter.");
+  struct _ac_state *n = *state;
+  ACMachine *m = n->machine;
+  ACM_REQUIRE (mtx_lock (&m->lock) == thrd_success, "");
+  uint32_t at = 0;
+  struct _ac_state *k = child_find (n, letter, &at);
+  if (k) {
+    if (m->letter_dtor) /* the edge exists: this copy of the letter is not kept, reference :306-307 */
+      m->letter_dtor (letter);
+  } else {
+    k = state_alloc (m);
+    k->parent = n;
+    k->letter = letter;
+    k->depth = n->depth + 1;
+    if (n->nkids == n->capkids) {
+      n->capkids = n->capkids ? 2 * n->capkids : 2;
+      n->kids = realloc (n->kids, n->capkids * sizeof *n->kids);
+      ACM_REQUIRE (n->kids, "Out of memory.");
+    }
+    memmove (n->kids + at + 1, n->kids + at, (n->nkids - at) * sizeof *n->kids);
+    n->kids[at] = k;
+    n->nkids++;
+    link_failure_of_new_leaf (n, k);
+    m->generation++;
+  }
+  *state = k;
+  ACM_REQUIRE (mtx_unlock (&m->lock) == thrd_success, "");
+}
+
+void *
+acm_insert_end_of_keyword (ACState **state, void *value, void (*dtor) (void *)) {
+  ACM_REQUIRE (state && *state, "Invalid null state.");
+  struct _ac_state *n = *state;
+  ACMachine *m = n->machine;
+  ACM_REQUIRE (mtx_lock (&m->lock) == thrd_success, "");
+  ACM_REQUIRE (n != m->root, "acm_insert_letter_of_keyword should be called first.");
+  if (!n->terminal) {
+    /* one more keyword ends at n and at every state that has n as a suffix, i.e. the whole
+     * failure subtree of n (reference enter_output, :330-338) */
+    struct walk todo = { 0 };
+    walk_push (&todo, n);
+    while (todo.n) {
+      struct _ac_state *x = todo.v[--todo.n];
+      x->nb_outputs++;
+      for (uint32_t i = 0; i < x->ninv; i++)
+        walk_push (&todo, x->inv[i]);
+    }
+    free (todo.v);
+    n->terminal = 1;
+    n->rank = (uint32_t)m->nb_keywords++;
+    m->generation++;
+  }
+  void *previous = n->value;
+  if (!n->value) { /* first non-NULL value wins, reference :357-359 */
+    n->value = value;
+    n->value_dtor = dtor;
+  }
+  *state = m->root;
+  ACM_REQUIRE (mtx_unlock (&m->lock) == thrd_success, "");
+  return previous;
+}
+
+size_t
+acm_match (const ACState **state, const void *letter) {
+  ACM_REQUIRE (state && *state && letter, "Invalid null state or letter.");
+  return (*state = automaton_step (*state, letter))->nb_outputs;
+}
+
+void
+acm_matcher_init (MatchHolder *matcher) {
+  ACM_REQUIRE (matcher, "Invalid null matcher.");
+  matcher->letters = 0;
+  matcher->length = 0;
+  matcher->value = 0;
+}
+
+void
+acm_matcher_release (MatchHolder *matcher) {
+  ACM_REQUIRE (matcher, "Invalid null matcher.");
+  free (matcher->letters);
+  acm_matcher_init (matcher);
+}
+
+void
+acm_get_match (const ACState *state, size_t index, MatchHolder *matcher) {
+  ACM_REQUIRE (state, "Invalid null state.");
+  ACM_REQUIRE (state->parent, "acm_match should be called first and acm_matcher_init called on the MatchHolder.");
+  ACM_REQUIRE (index < state->nb_outputs, "Index out of bounds.");
+  /* index-th keyword-terminal state along the failure chain, nearest (= longest) first
+   * (reference :459-466) */
+  const struct _ac_state *t = state;
+  for (size_t seen = 0;; t = t->fail) {
+    if (t->terminal && seen++ == index)
+      break;
+  }
+  if (!matcher)
+    return;
+  matcher->length = t->depth;
+  matcher->letters = realloc (matcher->letters, matcher->length * sizeof *matcher->letters);
+  ACM_REQUIRE (matcher->letters || !matcher->length, "Out of memory.");
+  size_t k = matcher->length;
+  for (const struct _ac_state *s = t; s->parent; s = s->parent)
+    matcher->letters[--k] = s->letter;
+  matcher->value = t->value;
+}
+
+size_t
+acm_nb_keywords (const ACMachine *machine) {
+  ACM_REQUIRE (machine, "Invalid null machine.");
+  return machine->nb_keywords;
+}
+
+/* ------------------------------------------------------------------ enumeration / debug */
+struct dfs_frame {
+  const struct _ac_state *s;
+  uint32_t next_kid;
+};
+
+void
+acm_foreach_keyword (const ACMachine *machine, void (*operator_) (MatchHolder)) {
+  ACM_REQUIRE (machine, "Invalid null machine.");
+  if (!operator_)
+    return;
+  /* iterative pre-order DFS in comparator order (reference :490-519) */
+  size_t cap = 16, top = 0;
+  struct dfs_frame *st = malloc (cap * sizeof *st);
+  const void **letters = malloc (cap * sizeof *letters);
+  ACM_REQUIRE (st && letters, "Out of memory.");
+  st[top++] = (struct dfs_frame){ machine->root, 0 };
+  while (top) {
+    struct dfs_frame *f = &st[top - 1];
+    if (f->next_kid == 0 && f->s->terminal && f->s->depth) {
+      MatchHolder k = { .letters = letters, .length = f->s->depth, .value = f->s->value };
+      operator_ (k);
+    }
+    if (f->next_kid < f->s->nkids) {
+      const struct _ac_state *kid = f->s->kids[f->next_kid++];
+      if (top == cap) {
+        cap *= 2;
+        st = realloc (st, cap * sizeof *st);
+        letters = realloc (letters, cap * sizeof *letters);
+        ACM_REQUIRE (st && letters, "Out of memory.");
+      }
+      letters[kid->depth - 1] = kid->letter;
+      st[top++] = (struct dfs_frame){ kid, 0 };
+    } else
+      top--;
+  }
+  free (st);
+  free (letters);
+}
+
+/* Tree drawing, same text as the reference's (:541-594): one edge is
+ *   ---<letter>-->(<id>)[+<outputs> if keyword end](v <fail id> if the failure link is not the root)
+ * the root id is printed in front of each of its edges; the first child continues the line, the
+ * next ones start a new line indented to their parent's column with an 'L' elbow. */
+static void
+print_subtree (const struct _ac_state *s, FILE *out, int *col, int indent, PRINT_TYPE printer) {
+  for (uint32_t i = 0; i < s->nkids; i++) {
+    const struct _ac_state *k = s->kids[i];
+    if (indent < *col) {
+      *col = 0;
+      fprintf (out, "\n");
+      if (indent) {
+        for (int t = 0; t < indent - 1; t++)
+          *col += fprintf (out, " ");
+        *col += fprintf (out, "L");
+      }
+    } else
+      while (*col < indent)
+        *col += fprintf (out, " ");
+    if (!s->parent)
+      *col += fprintf (out, "(%03zu)", (size_t)s->id);
+    *col += fprintf (out, "---");
+    if (printer)
+      *col += printer (out, k->letter);
+    *col += fprintf (out, "-->(%03zu)", (size_t)k->id);
+    if (k->terminal)
+      *col += fprintf (out, "[+%zu]", (size_t)k->nb_outputs);
+    if (k->fail != s->machine->root)
+      *col += fprintf (out, "(v %03zu)", (size_t)k->fail->id);
+    print_subtree (k, out, col, *col, printer);
+  }
+}
+
+void
+acm_print (ACMachine *machine, FILE *stream, PRINT_TYPE printer) {
+  ACM_REQUIRE (machine, "Invalid null machine.");
+  if (!stream)
+    return;
+  int col = 0;
+  fprintf (stream, "\n");
+  print_subtree (machine->root, stream, &col, 0, printer);
+  fprintf (stream, "\n");
+}

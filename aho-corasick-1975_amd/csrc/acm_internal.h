@@ -1,0 +1,50 @@
+/* Internal interface between the host trie (acm_host.c), the flattener (acm_flat.c) and the
+ * device side (acm_gpu.hip).  Not installed. */
+#ifndef ACM_INTERNAL_H
+#define ACM_INTERNAL_H
+
+#include "acm.h"
+#include "acm_gpu.h"
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct _ac_state {
+  ACMachine *machine;
+  struct _ac_state *parent; /* reference: previous.state, aho_corasick.c:49-52 */
+  void *letter;             /* symbol on the edge parent -> this, as handed in by the caller */
+  struct _ac_state *fail;   /* f(s); NULL for the root only */
+  struct _ac_state **kids;  /* goto edges: children ordered by the machine comparator on ->letter */
+  struct _ac_state **inv;   /* inverse failure set { x : f(x) == this }, unordered */
+  uint32_t nkids, capkids;
+  uint32_t ninv, capinv;
+  uint32_t inv_slot;        /* position of this state inside fail->inv (O(1) removal) */
+  uint32_t depth;
+  uint32_t nb_outputs;      /* keywords ending here = terminal + nb_outputs(fail) */
+  uint32_t rank;            /* keyword_id when terminal */
+  uint32_t id;              /* creation order, printed by acm_print */
+  int terminal;
+  void *value;
+  void (*value_dtor) (void *);
+};
+
+/* dictionary generation counter: bumped whenever a node or a keyword is added; a cached device
+ * plan built at another generation is stale. */
+uint64_t acm_internal_generation (const ACMachine *m);
+ACState *acm_internal_root (const ACMachine *m);
+uint32_t acm_internal_nb_states (const ACMachine *m);
+/* 0 if the machine uses ACM_CMP_DEFAULT over 1, 2 or 4 byte symbols, else ACM_GPU_E_INELIGIBLE */
+int acm_internal_symbol_bytes (const ACMachine *m, uint32_t *sym_bytes);
+void acm_internal_lock (ACMachine *m);
+void acm_internal_unlock (ACMachine *m);
+/* per-machine slot for the cached device plan (owned by acm_gpu.hip) */
+void **acm_internal_plan_slot (ACMachine *m);
+/* set by the device side once; called by acm_release to drop the cached plan */
+extern void (*acm_internal_plan_dropper) (void *plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,74 @@
+"""Sharding of one text over the ranks of a node and the gather of match records to a root.
+
+The scan cursor is the only scan state (reference aho_corasick.h:47,70: the caller owns the
+`const ACState *`), and after any position it is a function of the last lmax symbols only, so a
+text splits into independent contiguous shards: rank r owns [r*N/R, (r+1)*N/R), starts from the
+root lmax-1 symbols earlier and reports only matches that END inside its range.
+Tables are replicated.  The one exchange step is the variable-length gather of 16-byte records:
+an all-gather of the per-rank counts, then direct peer->root transfers (xGMI is point-to-point:
+7 links into the root, no ring).  Ranks own increasing, disjoint position ranges and each emits
+canonical order, so concatenation in rank order IS the canonical order -- no global sort.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_symbols, rank, world, lmax):
+    """(read_begin, own_begin, own_end): the rank scans [read_begin, own_end) from the root and
+    reports matches ending in [own_begin, own_end)."""
+    own_begin = n_symbols * rank // world
+    own_end = n_symbols * (rank + 1) // world
+    warm = max(lmax - 1, 0)
+    read_begin = max(own_begin - warm, 0)
+    return read_begin, own_begin, own_end
+
+
+def gather_records(local, group=None, dst=0):
+    """local: int64 tensor [n, 2] (16-byte records, canonical order, global end_pos).
+    Returns on `dst` the concatenation over ranks in rank order, elsewhere None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local.device
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    if world == 1:
+        return local
+    if rank == dst:
+        total = sum(counts)
+        out = torch.empty((total, 2), dtype=torch.int64, device=dev)
+        offs = [0]
+        for c in counts:
+            offs.append(offs[-1] + c)
+        out[offs[dst]:offs[dst + 1]] = local
+        ops = []
+        for r in range(world):
+            if r != dst and counts[r]:
+                ops.append(dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], _global_rank(r, group), group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return out
+    if counts[rank]:
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), _global_rank(dst, group), group)]):
+            req.wait()
+    return None
+
+
+def _global_rank(group_rank, group):
+    if group is None:
+        return group_rank
+    return dist.get_global_rank(group, group_rank)
+
+
+def scan_sharded(scan_fn, n_symbols, lmax, make_shard, group=None, dst=0):
+    """One sharded pass.  make_shard(read_begin, own_end) -> this rank's text for
+    [read_begin, own_end); scan_fn(text, emit_from, pos_base) -> int64 [n, 2] records in canonical
+    order whose end_pos is global.  Returns the gathered records on dst (None elsewhere)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    read_begin, own_begin, own_end = shard_bounds(n_symbols, rank, world, lmax)
+    text = make_shard(read_begin, own_end)
+    local = scan_fn(text, own_begin - read_begin, read_begin)
+    return gather_records(local, group, dst)

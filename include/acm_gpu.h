@@ -1,0 +1,172 @@
+/*
+ * acm_gpu.h -- bulk-scan extension of the acm_* API: the MI355X (gfx950) hot path.
+ *
+ * The reference has no buffer-level entry point: its hot path is the CALLER's loop
+ *
+ *     for (i = 0; i < n; i++)                                   examples/test.c:17-23
+ *       for (j = 0, nb = acm_match (&cursor, &text[i]); j < nb; j++)   aho_corasick.c:434-448
+ *         acm_get_match (cursor, j, &holder);                   aho_corasick.c:451-482
+ *
+ * Every scan function below is DEFINED as that loop started from acm_initiate(machine): it
+ * yields one ACMRecord per (i, j) with end_pos = i, length = holder.length and keyword_id = the
+ * 0-based rank of the keyword in order of first acm_insert_end_of_keyword (the value
+ * machine->nb_sequences had just before aho_corasick.c:352), in the loop's order
+ * (end_pos ascending, then j ascending == length descending).
+ *
+ * All of it runs on the GPU as hand-written HIP; there is NO CPU fallback: a machine the GPU
+ * path cannot take (comparator other than ACM_CMP_DEFAULT, symbol size not in {1,2,4}) or a
+ * missing device is reported as an error code and the caller keeps using the per-symbol API.
+ *
+ * Plain C ABI: pointers and sizes only.  `stream` arguments are a hipStream_t passed as void *
+ * (NULL = the default stream); `d_` pointers are device memory on the plan's device.
+ */
+#ifndef ACM_GPU_H_AMD
+#define ACM_GPU_H_AMD
+
+#include "acm.h"
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Canonical match record, 16 bytes. */
+typedef struct {
+  uint64_t end_pos;    /* index of the symbol at which the keyword ends */
+  uint32_t length;     /* MatchHolder.length of that match */
+  uint32_t keyword_id; /* first-insertion rank of the keyword */
+} ACMRecord;
+
+enum {
+  ACM_GPU_OK = 0,
+  ACM_GPU_E_INELIGIBLE = -1, /* comparator is not ACM_CMP_DEFAULT, or symbol size not 1/2/4 bytes */
+  ACM_GPU_E_NODEVICE = -2,   /* no usable HIP device */
+  ACM_GPU_E_HIP = -3,        /* a HIP call failed (message on stderr) */
+  ACM_GPU_E_OVERFLOW = -4,   /* more matches than `capacity`; the count output holds the number needed */
+  ACM_GPU_E_ARG = -5,        /* invalid argument */
+  ACM_GPU_E_NOMEM = -6
+};
+const char *acm_gpu_strerror (int code);
+int acm_gpu_device_count (void);
+
+/* ------------------------------------------------------------------ flattened tables (host)
+ * Snapshot of the machine's goto / failure / output functions as flat arrays (what
+ * struct _ac_state holds per node in the reference: transitions :47, fail_state :53,
+ * is_end_of_keyword :54, nb_outputs :55, previous :49-52).  States are renumbered breadth-first
+ * (root = 0, children in memcmp order), so shallow -- hot -- states get the small ids and
+ * depth(s) is monotone in s.  Needs no GPU. */
+typedef struct ACMFlat ACMFlat;
+
+typedef struct {
+  uint32_t sym_bytes;   /* 1, 2 or 4 */
+  uint32_t n_states;
+  uint32_t n_keywords;
+  uint32_t n_edges;     /* = n_states - 1 */
+  uint32_t lmax;        /* longest keyword, in symbols */
+  uint32_t max_outputs; /* max over states of nb_outputs */
+  uint32_t alpha_lo;    /* byte alphabets: smallest symbol used by any keyword */
+  uint32_t alpha_span;  /* byte alphabets: largest - smallest + 1 (0 for an empty machine) */
+  uint32_t width;       /* byte alphabets: dense row width = span + 1 ("other" class last), or 256 */
+} ACMFlatInfo;
+
+typedef struct {
+  const uint32_t *row_ptr;     /* [n_states + 1] CSR of the goto function */
+  const uint32_t *edge_sym;    /* [n_edges] symbol value (little-endian read of sym_bytes bytes), ascending memcmp order per row */
+  const uint32_t *edge_next;   /* [n_edges] g(state, symbol) */
+  const uint32_t *fail;        /* [n_states] f(state); f(root) = 0 */
+  const uint32_t *depth;       /* [n_states] */
+  const uint32_t *nb_outputs;  /* [n_states] what acm_match returns in that state */
+  const uint32_t *term_kw;     /* [n_states] keyword_id if a keyword ends here, else 0xFFFFFFFF */
+  const uint32_t *out_link;    /* [n_states] nearest keyword-terminal state strictly down the failure chain, 0 if none */
+  const uint32_t *depth_start; /* [lmax + 2] first state id of each depth; depth_start[lmax + 1] = n_states */
+  const uint32_t *kw_state;    /* [n_keywords] terminal state of each keyword */
+} ACMFlatView;
+
+int acm_flatten (ACMachine *machine, ACMFlat **out);
+void acm_flat_release (ACMFlat *flat);
+void acm_flat_info (const ACMFlat *flat, ACMFlatInfo *info);
+void acm_flat_view (const ACMFlat *flat, ACMFlatView *view);
+/* Failure-resolved (DFA) rows of states [0, n_rows) of a byte-alphabet machine:
+ * out[s * width + cls] = delta(s, alpha_lo + cls) | (nb_outputs(next) ? top bit : 0), class
+ * `span` (when width == span + 1) standing for every symbol outside [lo, lo + span).
+ * entry_bytes is 2 (n_states <= 32768) or 4. */
+int acm_flat_dense_rows (const ACMFlat *flat, uint32_t n_rows, uint32_t entry_bytes, void *out);
+
+/* ------------------------------------------------------------------ device plan */
+typedef struct ACMPlan ACMPlan;
+
+typedef struct {
+  int device;
+  uint32_t kernel;       /* 1 = dense-row byte kernel (LDS-resident hot rows), 2 = CSR kernel (any symbol size) */
+  uint32_t entry_bytes;  /* dense entries: 2 or 4 */
+  uint32_t width;        /* dense row width */
+  uint32_t dense_rows;   /* rows resident in HBM */
+  uint32_t lds_rows;     /* of which staged in LDS by every workgroup */
+  uint32_t lds_bytes;    /* dynamic LDS per workgroup */
+  uint32_t block_threads;
+  uint32_t grid_blocks;
+  uint32_t chunk_bytes;  /* text bytes per lane-stream per tile */
+  uint32_t streams;      /* independent streams per lane */
+  uint64_t table_bytes;  /* device bytes held by the plan */
+} ACMPlanInfo;
+
+/* Flattens `machine` and uploads the tables to `device`.  The plan is a snapshot: keywords
+ * inserted later are not seen by it. */
+int acm_gpu_plan_create (ACMachine *machine, int device, ACMPlan **out);
+int acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out);
+void acm_gpu_plan_destroy (ACMPlan *plan);
+void acm_gpu_plan_info (const ACMPlan *plan, ACMPlanInfo *info);
+
+/* Scan d_text[0 .. n_symbols) from the root state.  Matches whose end index is < emit_from are
+ * not reported (warm-up region of a shard: pass the lmax - 1 symbols preceding the shard and
+ * emit_from = their number).  Reported end_pos = pos_base + index - emit_from... see below.
+ *
+ *   end_pos of a match ending at buffer index i  =  pos_base + i
+ *
+ * Records are appended to d_records in no particular order (at most `capacity`); *d_count
+ * (device, 8 bytes) receives the TOTAL number of matches, which may exceed capacity -- nothing is
+ * dropped silently: compare and re-run with a larger buffer.  Asynchronous on `stream`. */
+int acm_gpu_scan_device (ACMPlan *plan, const void *d_text, uint64_t n_symbols, uint64_t emit_from,
+                         uint64_t pos_base, ACMRecord *d_records, uint64_t capacity,
+                         uint64_t *d_count, void *stream);
+
+/* Sum of acm_match return values over the buffer (reference: generic_test.c:272-273), no records. */
+int acm_gpu_count_device (ACMPlan *plan, const void *d_text, uint64_t n_symbols, uint64_t emit_from,
+                          uint64_t *d_count, void *stream);
+
+/* Puts n records into canonical order (end_pos ascending, length descending) in place.
+ * d_tmp must hold acm_gpu_sort_tmp_bytes(n) bytes.  Asynchronous on `stream`. */
+size_t acm_gpu_sort_tmp_bytes (uint64_t n);
+int acm_gpu_sort_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, void *d_tmp,
+                                 size_t tmp_bytes, void *stream);
+
+/* Host-buffer convenience: upload, scan, sort, download; blocking.  On ACM_GPU_E_OVERFLOW
+ * *n_found holds the capacity needed. */
+int acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint64_t emit_from,
+                       uint64_t pos_base, ACMRecord *records, uint64_t capacity, uint64_t *n_found);
+
+/* The bulk call on the machine itself: keeps a plan cached inside the machine and rebuilds it
+ * when the dictionary changed since the last call.  Device = $ACM_GPU_DEVICE or 0. */
+int acm_scan (ACMachine *machine, const void *text, uint64_t n_symbols, ACMRecord *records,
+              uint64_t capacity, uint64_t *n_found);
+
+/* Kernel timing with HIP events recorded on the launch stream around the scan kernel only.
+ * Enable, run scans, then read: total milliseconds and number of launches since enabling.
+ * Reading synchronises on the recorded events. */
+int acm_gpu_plan_timing (ACMPlan *plan, int enable);
+int acm_gpu_plan_timing_read (ACMPlan *plan, double *total_ms, uint64_t *launches);
+
+/* ------------------------------------------------------------------ synthetic workload (bench/test tooling)
+ * text[i] = 'a' + sm(i + 42) % 26, one keyword planted per 4096-symbol block.
+ * Generates d_text[0 .. n) for global indices [global_begin, global_begin + n); global_begin must
+ * be a multiple of 4096.  kw_data/kw_off: the K keywords packed on the DEVICE (symbols of
+ * sym_bytes each; kw_off has K + 1 entries).  For sym_bytes == 4 the unplanted symbol is
+ * sm(i + 42) % vocab. */
+int acm_gpu_synth_text (int device, void *d_text, uint64_t n, uint64_t global_begin, uint32_t sym_bytes,
+                        uint32_t vocab, const void *d_kw_data, const uint32_t *d_kw_off, uint32_t n_kw,
+                        void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
