@@ -1,0 +1,212 @@
+"""GPU parity: the HIP bulk scan (through the C ABI of include/acm_gpu.h) against the CPU oracle's
+caller loop on the same inputs -- bit-exact records in canonical order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import aho_corasick_1975_amd as acm
+from oracle import pyoracle as po
+from tests.cases import build_pair, build_pair_packed, small_cases
+
+pytestmark = pytest.mark.gpu
+
+CASES = small_cases()
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run with -m gpu on the GPU box)"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _dev(torch, arr):
+    a = np.frombuffer(bytes(arr), dtype=np.uint8) if isinstance(arr, (bytes, bytearray)) else np.ascontiguousarray(arr)
+    if a.dtype == np.uint16:
+        a = a.view(np.int16)
+    elif a.dtype == np.uint32:
+        a = a.view(np.int32)
+    return torch.from_numpy(a.copy()).cuda()
+
+
+def test_native_library_is_loaded_and_sees_the_gpu(torch_cuda):
+    assert acm.lib().acm_gpu_device_count() >= 1
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_small_cases_bit_exact(torch_cuda, name):
+    kws, text, sym = CASES[name]
+    m, o = build_pair(kws, sym)
+    want = o.scan(text)
+    plan = m.plan(0)
+    got = plan.scan_sorted(_dev(torch_cuda, text))
+    assert got.size == want.size
+    assert np.array_equal(got, want)
+    # count-only entry point == sum of acm_match (generic_test.c:272-273)
+    cnt = plan.count(_dev(torch_cuda, text))
+    assert int(cnt.item()) == o.count(text) == want.size
+    # host-buffer C ABI path (no torch involved)
+    assert np.array_equal(plan.scan_host(np.frombuffer(bytes(text), np.uint8) if isinstance(text, bytes) else text), want)
+
+
+def test_acm_scan_on_machine_follows_dictionary_updates(torch_cuda):
+    """acm_scan() caches a plan inside the machine and rebuilds it when keywords were added."""
+    m, o = build_pair([b"he", b"she"], 1)
+    text = b"ushers and heroes; she sells hers" * 50
+    assert np.array_equal(m.scan_host(text), o.scan(text))
+    for w in (b"his", b"hers", b"s"):
+        m.add_keyword(w)
+        o.add_keyword(w)
+    assert np.array_equal(m.scan_host(text), o.scan(text))
+
+
+def test_config1_novel(torch_cuda, novel_bytes):
+    """BASELINE config 1 on the GPU path: 11,676 records, identical to the oracle's."""
+    m, o = build_pair([b"he", b"she", b"his", b"hers"], 1)
+    got = m.plan(0).scan_sorted(_dev(torch_cuda, novel_bytes))
+    assert got.size == 11676
+    assert np.array_equal(got, o.scan(novel_bytes))
+    assert np.bincount(got["keyword_id"]).tolist() == [9513, 1273, 784, 106]
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 15, 16, 17, 8191, 8192, 8193, 16384 + 7, 3 * 8192 + 100, 1 << 20])
+def test_ragged_lengths_and_tile_seams(torch_cuda, n):
+    """Head/tail ranges and tile seams of the dense kernel: every length around the 8 KiB tile."""
+    kd, ko = acm.synth.keywords(300)
+    m, o = build_pair_packed(kd, ko)
+    text = acm.synth.text(((n + 4095) // 4096 + 1) * 4096, kd, ko)[:n]
+    plan = m.plan(0)
+    got = plan.scan_sorted(_dev(torch_cuda, text)) if n else plan.scan_host(text)
+    assert np.array_equal(got, o.scan(text))
+
+
+def test_keywords_across_every_seam(torch_cuda):
+    """Plant one keyword across each chunk boundary (64 B) of a few tiles."""
+    kws = [b"abcdefghijkl", b"ghij", b"l", b"kla"]
+    m, o = build_pair(kws, 1)
+    n = 4 * 8192 + 1000
+    text = np.full(n, ord("x"), dtype=np.uint8)
+    for p in range(58, n - 12, 64):
+        text[p:p + 12] = np.frombuffer(b"abcdefghijkl", np.uint8)
+    got = m.plan(0).scan_sorted(_dev(torch_cuda, text))
+    assert np.array_equal(got, o.scan(text))
+
+
+def test_emit_from_and_pos_base(torch_cuda):
+    kd, ko = acm.synth.keywords(300)
+    m, o = build_pair_packed(kd, ko)
+    text = acm.synth.text(1 << 18, kd, ko)
+    full = o.scan(text)
+    plan = m.plan(0)
+    for cut in (0, 11, 4096, 100001):
+        got = plan.scan_sorted(_dev(torch_cuda, text), emit_from=cut, pos_base=1 << 40)
+        ref = full[full["end_pos"] >= cut].copy()
+        ref["end_pos"] += np.uint64(1 << 40)
+        assert np.array_equal(got, ref)
+
+
+def test_overflow_is_reported_not_silent(torch_cuda):
+    m, o = build_pair([b"a", b"aa"], 1)
+    text = np.full(100000, ord("a"), dtype=np.uint8)
+    plan = m.plan(0)
+    rec, cnt = plan.scan(_dev(torch_cuda, text), capacity=1000)
+    torch_cuda.cuda.synchronize()
+    assert int(cnt.item()) == 199999 > rec.shape[0]
+    out = np.zeros(10, dtype=acm.RECORD_DTYPE)
+    n = C.c_uint64(0)
+    rc = acm.lib().acm_gpu_scan_host(plan.h, text.ctypes.data, text.size, 0, 0, out.ctypes.data, 10, C.byref(n))
+    assert rc == -4 and n.value == 199999
+    assert np.array_equal(plan.scan_sorted(_dev(torch_cuda, text)), o.scan(text))
+
+
+def test_dense_matches_everywhere(torch_cuda):
+    """Output blow-up: nested keywords matching at every position (queue flush path)."""
+    kws = [b"a" * k for k in range(1, 9)] + [b"ab", b"b"]
+    m, o = build_pair(kws, 1)
+    rng = np.random.default_rng(5)
+    text = rng.choice(np.frombuffer(b"aaab", np.uint8), size=200000)
+    assert np.array_equal(m.plan(0).scan_sorted(_dev(torch_cuda, text)), o.scan(text))
+
+
+def test_rows_colder_than_lds(torch_cuda):
+    """A dictionary whose rows do not all fit in LDS: transitions through HBM-resident rows."""
+    rng = np.random.default_rng(9)
+    kws = [bytes(rng.integers(97, 123, size=int(rng.integers(4, 13)), dtype=np.uint8)) for _ in range(6000)]
+    m, o = build_pair(kws, 1)
+    plan = m.plan(0)
+    assert plan.info.kernel == 1 and plan.info.lds_rows < plan.info.dense_rows
+    text = rng.integers(97, 123, size=1 << 20, dtype=np.uint8)
+    for p in range(100, text.size - 16, 997):          # make deep states common
+        w = kws[int(rng.integers(0, len(kws)))]
+        text[p:p + len(w)] = np.frombuffer(w, np.uint8)
+    assert np.array_equal(plan.scan_sorted(_dev(torch_cuda, text)), o.scan(text))
+
+
+def test_config2_shape_64MiB_digest(torch_cuda):
+    """BASELINE config 2's dictionary (1k keywords) on a 64 MiB prefix of its text: count and
+    order-independent digest of SURVEY.md App. C (35,453 / 75c631ca92f2fd08), text generated on
+    the device by acm_gpu_synth_text."""
+    kd, ko = acm.synth.keywords(1000)
+    m = acm.Machine(1)
+    m.add_keywords_packed(kd, ko)
+    n = 1 << 26
+    text = acm.synth.device_text(n, kd, ko)
+    assert np.array_equal(text[:1 << 16].cpu().numpy(), acm.synth.text(1 << 16, kd, ko))
+    got = m.plan(0).scan_sorted(text)
+    assert got.size == 35453 and po.digest(got) == 0x75c631ca92f2fd08
+    assert np.all(np.diff(got["end_pos"].astype(np.int64)) >= 0)
+
+
+def test_config2_full_size_properties(torch_cuda):
+    """Full 1 GiB of config 2: size-independent properties -- the count is additive over
+    4096-aligned shards scanned with lmax-1 warm-up, records are sorted, and the digest of the
+    whole equals the sum of shard digests."""
+    kd, ko = acm.synth.keywords(1000)
+    m = acm.Machine(1)
+    m.add_keywords_packed(kd, ko)
+    plan = m.plan(0)
+    n = 1 << 30
+    text = acm.synth.device_text(n, kd, ko)
+    whole = plan.scan_sorted(text)
+    assert np.all(np.diff(whole["end_pos"].astype(np.int64)) >= 0)
+    parts, warm = [], m.lmax - 1
+    for r in range(4):
+        b, e = n * r // 4, n * (r + 1) // 4
+        rb = max(b - warm, 0)
+        parts.append(plan.scan_sorted(text[rb:e], emit_from=b - rb, pos_base=rb))
+    cat = np.concatenate(parts)
+    assert cat.size == whole.size
+    assert np.array_equal(cat, whole)
+    assert int(plan.count(text).item()) == whole.size
+    # first 64 MiB of the stream is the survey's known-answer prefix
+    head = whole[whole["end_pos"] < (1 << 26)]
+    assert head.size == 35453 and po.digest(head) == 0x75c631ca92f2fd08
+
+
+def test_u32_config5_shape(torch_cuda):
+    """BASELINE config 5 shape at test size: uint32 symbols, vocab 32,768, 10k keywords."""
+    kd, ko = acm.synth.keywords(10000, sym_bytes=4)
+    m, o = build_pair_packed(kd, ko, sym_size=4)
+    n = 1 << 20
+    text = acm.synth.text(n, kd, ko, sym_bytes=4)
+    dev = acm.synth.device_text(n, kd, ko, sym_bytes=4)
+    assert np.array_equal(dev.cpu().numpy().view(np.uint32), text)
+    plan = m.plan(0)
+    assert plan.info.kernel == 2
+    assert np.array_equal(plan.scan_sorted(dev), o.scan(text))
+
+
+def test_100k_dictionary_config3_shape(torch_cuda):
+    """BASELINE config 3's dictionary (100k keywords, 508,339 states) on 16 MiB of its text."""
+    kd, ko = acm.synth.keywords(100000)
+    m, o = build_pair_packed(kd, ko, variant=po.MEYER85)
+    n = 1 << 24
+    text = acm.synth.text(n, kd, ko)
+    plan = m.plan(0)
+    got = plan.scan_sorted(_dev(torch_cuda, text))
+    cnt, dig = o.scan_mt(text, 8)
+    assert got.size == cnt and po.digest(got) == dig
+    want_head = o.scan(text[:1 << 20])
+    assert np.array_equal(got[got["end_pos"] < (1 << 20)], want_head)
