@@ -178,7 +178,7 @@ uniform (uint32_t v) { /* tells the compiler the value is the same in every lane
  * cold state (its LDS lookup was meaningless and is redone from the HBM copy here). */
 template <typename ENTRY, int S, bool COUNT_ONLY>
 __device__ __forceinline__ void
-dense_step_slow (const DenseK &K, const EmitCtx &E, uint64_t emit_from, const ENTRY *__restrict__ gdense, uint4 *queue,
+dense_step_slow (const DenseK &K, const EmitCtx &E, uint64_t emit_from, uint64_t emit_end, const ENTRY *__restrict__ gdense, uint4 *queue,
                  Walk<S> &w, uint32_t (&e)[S], const uint32_t (&cls)[S], uint32_t j, bool emit, uint32_t lane) {
   constexpr uint32_t FLAG = EntryTraits<ENTRY>::FLAG;
   constexpr uint32_t IDMASK = FLAG - 1;
@@ -189,7 +189,7 @@ dense_step_slow (const DenseK &K, const EmitCtx &E, uint64_t emit_from, const EN
       e[q] = gdense[w.s[q] * K.W + cls[q]];
     const uint32_t ns = e[q] & IDMASK;
     const uint64_t pos = w.cs[q] + j;
-    const bool hit = emit && (e[q] & FLAG) && pos >= emit_from;
+    const bool hit = emit && (e[q] & FLAG) && pos >= emit_from && pos < emit_end;
     const uint64_t m = __ballot (hit);
     if (m) {
       if (hit)
@@ -211,7 +211,7 @@ dense_step_slow (const DenseK &K, const EmitCtx &E, uint64_t emit_from, const EN
  * row(state) + class; all streams share one compare-and-branch. */
 template <typename ENTRY, int S, bool COUNT_ONLY>
 __device__ __forceinline__ void
-dense_step (const DenseK &K, const EmitCtx &E, uint64_t emit_from, const unsigned char *lds,
+dense_step (const DenseK &K, const EmitCtx &E, uint64_t emit_from, uint64_t emit_end, const unsigned char *lds,
             const ENTRY *__restrict__ gdense, uint4 *queue, Walk<S> &w, const uint32_t (&b)[S], uint32_t j, bool emit,
             uint32_t lane) {
   uint32_t cls[S], e[S];
@@ -230,7 +230,7 @@ dense_step (const DenseK &K, const EmitCtx &E, uint64_t emit_from, const unsigne
   for (int q = 0; q < S; q++)
     emax = max (emax, e[q]);
   if (__builtin_expect (__ballot (emax >= K.HL) != 0, 0))
-    dense_step_slow<ENTRY, S, COUNT_ONLY> (K, E, emit_from, gdense, queue, w, e, cls, j, emit, lane);
+    dense_step_slow<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, e, cls, j, emit, lane);
   else {
 #pragma unroll
     for (int q = 0; q < S; q++)
@@ -241,14 +241,14 @@ dense_step (const DenseK &K, const EmitCtx &E, uint64_t emit_from, const unsigne
 /* 16 steps over one 16-byte block per stream */
 template <typename ENTRY, int S, bool COUNT_ONLY>
 __device__ __forceinline__ void
-dense_block (const DenseK &K, const EmitCtx &E, uint64_t emit_from, const unsigned char *tab,
+dense_block (const DenseK &K, const EmitCtx &E, uint64_t emit_from, uint64_t emit_end, const unsigned char *tab,
              const ENTRY *__restrict__ gdense, uint4 *queue, Walk<S> &w, const uint4 (&blk)[S], uint32_t j0, bool emit,
              uint32_t lane) {
 #define ACM_BYTE(COMP, SH, J)                                                                      \
   {                                                                                                \
     uint32_t b_[S];                                                                                \
     _Pragma ("unroll") for (int q = 0; q < S; q++) b_[q] = (blk[q].COMP >> (SH)) & 0xffu;          \
-    dense_step<ENTRY, S, COUNT_ONLY> (K, E, emit_from, tab, gdense, queue, w, b_, j0 + (J), emit, lane); \
+    dense_step<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, tab, gdense, queue, w, b_, j0 + (J), emit, lane); \
   }
 #define ACM_WORD(COMP, J)                                                                          \
   ACM_BYTE (COMP, 0, (J) + 0) ACM_BYTE (COMP, 8, (J) + 1) ACM_BYTE (COMP, 16, (J) + 2) ACM_BYTE (COMP, 24, (J) + 3)
@@ -257,14 +257,33 @@ dense_block (const DenseK &K, const EmitCtx &E, uint64_t emit_from, const unsign
 #undef ACM_BYTE
 }
 
+/* compile-time loop over the C/16 blocks of a chunk (keeps the text registers statically indexed) */
+template <typename ENTRY, int S, bool COUNT_ONLY, int K0, int KN> struct BlockLoop {
+  static __device__ __forceinline__ void
+  run (const DenseK &K, const EmitCtx &E, uint64_t emit_from, uint64_t emit_end, const unsigned char *tab,
+       const ENTRY *__restrict__ gdense, uint4 *queue, Walk<S> &w, const uint4 (&d)[KN][S], uint32_t lane) {
+    dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, tab, gdense, queue, w, d[K0], 16 * K0, true, lane);
+    BlockLoop<ENTRY, S, COUNT_ONLY, K0 + 1, KN>::run (K, E, emit_from, emit_end, tab, gdense, queue, w, d, lane);
+  }
+};
+template <typename ENTRY, int S, bool COUNT_ONLY, int KN> struct BlockLoop<ENTRY, S, COUNT_ONLY, KN, KN> {
+  static __device__ __forceinline__ void
+  run (const DenseK &, const EmitCtx &, uint64_t, uint64_t, const unsigned char *, const ENTRY *__restrict__, uint4 *,
+       Walk<S> &, const uint4 (&)[KN][S], uint32_t) {}
+};
+
+/* Tiles [range_begin, range_end) of 64*S*C bytes cover the whole buffer, the last one possibly
+ * ragged.  16-byte loads are clamped to the last block that holds a valid byte (an aligned
+ * 16-byte block never straddles a page, so it cannot fault); what a lane walks beyond the end of
+ * the buffer is never reported (emit window [emit_from, n)). */
 template <typename ENTRY, int C, int S, bool COUNT_ONLY>
 __global__ __launch_bounds__ (DENSE_THREADS) void
 scan_dense_kernel (DevTables T, ScanArgs A, const ENTRY *__restrict__ gdense, const unsigned char *__restrict__ text,
                    uint32_t queue_off) {
-  static_assert (C == 64, "the tile body below is written for 4 blocks of 16 bytes");
   extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
   const unsigned char *tab = smem;
   constexpr uint32_t TILE = WAVE * S * C;
+  constexpr int NB = C / 16;
 
   /* stage the hottest rows: a straight 16-byte-per-lane copy (the source is padded to 16 bytes) */
   {
@@ -285,7 +304,8 @@ scan_dense_kernel (DevTables T, ScanArgs A, const ENTRY *__restrict__ gdense, co
   const uint32_t wub = (T.lmax > 1 ? (T.lmax - 1 + 15) / 16 : 0); /* warm-up blocks of 16 bytes */
   const DenseK K = { T.width, T.width * (uint32_t)sizeof (ENTRY), T.lo, T.span, T.lds_rows };
   const EmitCtx E = make_emit_ctx (T, A);
-  const uint64_t emit_from = A.emit_from;
+  const uint64_t emit_from = A.emit_from, emit_end = A.n;
+  const uint64_t last_block = (A.n - 1) & ~15ull; /* byte offset of the last 16-byte block with a valid byte */
 
   Walk<S> w;
   w.qn = 0;
@@ -293,32 +313,50 @@ scan_dense_kernel (DevTables T, ScanArgs A, const ENTRY *__restrict__ gdense, co
 
   for (uint64_t tile = A.range_begin + wave; tile < A.range_end; tile += nwaves) {
     const uint64_t tbase = tile * TILE;
-    uint4 d0[S], d1[S], d2[S], d3[S];
+    uint4 d[NB][S];
 #pragma unroll
     for (int q = 0; q < S; q++) {
       w.cs[q] = tbase + (uint64_t)(q * WAVE + lane) * C;
-      const uint4 *p = reinterpret_cast<const uint4 *> (text + w.cs[q]);
-      d0[q] = p[0];
-      d1[q] = p[1];
-      d2[q] = p[2];
-      d3[q] = p[3];
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        const uint64_t off = w.cs[q] + 16 * k;
+        d[k][q] = *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
+      }
       w.s[q] = 0;
     }
     w.sticky = 0;
-    /* warm-up: wub 16-byte blocks before each chunk, from the root; outputs are not reported
-     * (they end in the previous chunk, whose owner reports them).  Tiles given to this kernel
-     * never start before buffer index 16 * wub. */
+    /* pull the wave's next tile towards L2 while this one is walked: one dword per lane-stream
+     * touches every 64-byte half line of it */
+    uint32_t touch[S];
+    {
+      const uint64_t nbase = tbase + nwaves * TILE;
+#pragma unroll
+      for (int q = 0; q < S; q++) {
+        const uint64_t off = nbase + (uint64_t)(q * WAVE + lane) * C;
+        touch[q] = *reinterpret_cast<const uint32_t *> (text + (off < last_block ? off : last_block));
+      }
+    }
+    /* warm-up: wub 16-byte blocks before each chunk, walked from the root without reporting
+     * (matches ending there belong to the previous chunk's owner).  A chunk closer than that to
+     * the start of the buffer starts from the root at its first in-range block instead. */
     for (uint32_t b = wub; b >= 1; b--) {
       uint4 pre[S];
 #pragma unroll
+      for (int q = 0; q < S; q++) {
+        const uint64_t back = 16ull * b;
+        const uint64_t off = w.cs[q] >= back ? w.cs[q] - back : 0;
+        pre[q] = *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
+      }
+      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, tab, gdense, queue, w, pre, 0, false, lane);
+#pragma unroll
       for (int q = 0; q < S; q++)
-        pre[q] = *reinterpret_cast<const uint4 *> (text + w.cs[q] - 16ull * b);
-      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, tab, gdense, queue, w, pre, 0, false, lane);
+        if (w.cs[q] < 16ull * b)
+          w.s[q] = 0;
     }
-    dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, tab, gdense, queue, w, d0, 0, true, lane);
-    dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, tab, gdense, queue, w, d1, 16, true, lane);
-    dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, tab, gdense, queue, w, d2, 32, true, lane);
-    dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, tab, gdense, queue, w, d3, 48, true, lane);
+    BlockLoop<ENTRY, S, COUNT_ONLY, 0, NB>::run (K, E, emit_from, emit_end, tab, gdense, queue, w, d, lane);
+#pragma unroll
+    for (int q = 0; q < S; q++)
+      asm volatile("" ::"v"(touch[q])); /* keeps the prefetch loads alive; they landed long ago */
   }
   flush_queue<COUNT_ONLY> (E, queue, w.qn);
 }
@@ -780,35 +818,30 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   a.count = reinterpret_cast<unsigned long long *> (d_count);
 
   const uint64_t TILE = (uint64_t)WAVE * DENSE_S * DENSE_C;
-  uint64_t fast_begin = 0, fast_end = 0; /* tile indices */
   if (p->info.kernel == 1 && (reinterpret_cast<uintptr_t> (d_text) & 15) == 0) {
-    const uint64_t wu = p->finfo.lmax > 1 ? ((p->finfo.lmax - 1 + 15) / 16) * 16 : 0;
-    fast_begin = (wu + TILE - 1) / TILE;
-    fast_end = n / TILE;
-    if (fast_end <= fast_begin)
-      fast_begin = fast_end = 0;
-  }
-  if (fast_end > fast_begin) {
-    int rc = launch_csr<COUNT_ONLY> (p, a, 0, fast_begin * TILE, st);
-    if (rc)
-      return rc;
+    /* one launch covers the whole buffer, ragged last tile included */
     ScanArgs f = a;
-    f.range_begin = fast_begin;
-    f.range_end = fast_end;
+    f.range_begin = 0;
+    f.range_end = (n + TILE - 1) / TILE;
     hipEvent_t stop;
-    rc = timing_begin (p, st, &stop);
+    int rc = timing_begin (p, st, &stop);
     if (rc)
       return rc;
+    uint32_t grid = p->info.grid_blocks;
+    const uint64_t waves_needed = f.range_end;
+    const uint64_t blocks_needed = (waves_needed + DENSE_THREADS / WAVE - 1) / (DENSE_THREADS / WAVE);
+    if (blocks_needed < grid)
+      grid = (uint32_t)blocks_needed;
     if (p->T.entry_bytes == 2)
-      hipLaunchKernelGGL (dense_kernel16 (COUNT_ONLY), dim3 (p->info.grid_blocks), dim3 (DENSE_THREADS), p->info.lds_bytes, st, p->T, f,
+      hipLaunchKernelGGL (dense_kernel16 (COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), p->info.lds_bytes, st, p->T, f,
                           static_cast<const uint16_t *> (p->T.dense), f.text, p->queue_off);
     else
-      hipLaunchKernelGGL (dense_kernel32 (COUNT_ONLY), dim3 (p->info.grid_blocks), dim3 (DENSE_THREADS), p->info.lds_bytes, st, p->T, f,
+      hipLaunchKernelGGL (dense_kernel32 (COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), p->info.lds_bytes, st, p->T, f,
                           static_cast<const uint32_t *> (p->T.dense), f.text, p->queue_off);
     HIP_TRY (hipGetLastError ());
     if (stop)
       HIP_TRY (hipEventRecord (stop, st));
-    return launch_csr<COUNT_ONLY> (p, a, fast_end * TILE, n, st);
+    return ACM_GPU_OK;
   }
   hipEvent_t stop;
   int rc = timing_begin (p, st, &stop);
