@@ -22,7 +22,8 @@ class ACMError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, _LIBNAME)
+    # ACM_NATIVE_LIB lets tools/ load the diagnostic build (libac75_amd_diag.so) instead
+    return os.environ.get("ACM_NATIVE_LIB") or os.path.join(_HERE, _LIBNAME)
 
 
 def build_native(force=False):
@@ -51,7 +52,7 @@ class FlatView(C.Structure):
 
 class PlanInfo(C.Structure):
     _fields_ = [("device", C.c_int)] + [(n, C.c_uint32) for n in (
-        "kernel", "entry_bytes", "width", "dense_rows", "lds_rows", "lds_bytes", "block_threads", "grid_blocks",
+        "kernel", "entry_bytes", "width", "dense_rows", "lds_rows", "lds_hotfail", "lds_bytes", "block_threads", "grid_blocks",
         "chunk_bytes", "streams")] + [("table_bytes", C.c_uint64)]
 
 

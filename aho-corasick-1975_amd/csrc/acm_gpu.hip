@@ -7,15 +7,16 @@
  * (acm_get_match, aho_corasick.c:459-466), emitting one 16-byte record per match.
  *
  * Kernels
- *   scan_dense_kernel  byte alphabets.  Failure-resolved rows (one lookup per symbol), the
- *                      shallowest rows staged in LDS by every workgroup, colder rows read from
- *                      the HBM/L2-resident copy.  A wave owns tiles of 64*S*C contiguous bytes;
- *                      each lane walks S independent chunks of C bytes held in registers
- *                      (dwordx4 loads), restarting from the root WU >= lmax-1 bytes before its
- *                      chunk and reporting only matches that end inside the chunk.
- *   scan_csr_kernel    any symbol width (1/2/4 bytes): goto/failure walk over the CSR arrays; also
- *                      covers the head and tail of the text that do not fill whole tiles.
- *   expand/flush       states-with-outputs are queued per wave in LDS as (position, state) and
+ *   scan_dense_kernel  byte alphabets.  One workgroup of 16 waves per CU keeps the automaton in
+ *                      LDS in two forms: failure-resolved rows (one ds_read per symbol) for the
+ *                      shallow, hot states and 8-byte {child, failure} records for deep states
+ *                      with at most one child; states that fit neither are walked through the
+ *                      HBM/L2-resident failure-resolved rows.  A wave owns tiles of 64*S*C
+ *                      contiguous bytes; each lane walks S independent chunks of C bytes held in
+ *                      registers (dwordx4 loads), restarting from the root >= lmax-1 bytes
+ *                      before its chunk and reporting only matches that end inside the chunk.
+ *   scan_csr_kernel    any symbol width (1/2/4 bytes): goto/failure walk over the CSR arrays.
+ *   flush_queue        states-with-outputs are queued per wave in LDS as (position, state) and
  *                      expanded to records with one global atomic per <= 64 queue entries
  *                      (wave prefix sum), never one atomic per match.
  *   sort               canonical order (end_pos asc, length desc) by a 64-bit radix sort
@@ -25,11 +26,11 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <vector>
 
 #include "acm_internal.h"
@@ -44,37 +45,76 @@
     }                                                                                              \
   } while (0)
 
+/* Diagnostic build only (-DACM_DIAG, libac75_amd_diag.so, used by tools/): per-wave cycle stamps.
+ * [0] kernel cycles, [1] cycles inside flush_queue, [2] flush calls, [3] slow-side steps,
+ * [4] cycles inside the slow side (flushes included), [5] cycles waiting for the tile's text,
+ * [6] tiles.  Nothing of this exists in the product build. */
+#ifdef ACM_DIAG
+__device__ unsigned long long g_acm_diag[8192][8];
+#define DIAG(...) __VA_ARGS__
+#else
+#define DIAG(...)
+#endif
+
 namespace {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
-constexpr int QCAP = 128;          /* per-wave queue of (pos, state) items, 16 B each */
+constexpr int QCAP = 128;           /* per-wave queue of (position, state) items, 8 B each */
 constexpr int DENSE_THREADS = 1024; /* one workgroup per CU, 16 waves */
 constexpr int DENSE_C = 64;         /* bytes per lane-stream per tile */
-constexpr int DENSE_S = 2;          /* independent streams per lane */
+constexpr uint64_t SEGMENT = 1ull << 31; /* symbols per launch: positions inside a launch are 32-bit */
 
-struct DevTables {
-  const uint32_t *row_ptr, *edge_sym, *edge_next, *fail, *depth, *nb_outputs, *term_kw, *out_link;
-  const void *dense; /* [dense_rows * width] entries of entry_bytes */
-  uint32_t n_states, width, lo, span, dense_rows, lds_rows, lmax, entry_bytes;
+/* tables of the CSR kernel, states in breadth-first numbering (ACMFlatView) */
+struct CsrTables {
+  const uint32_t *row_ptr, *edge_sym, *edge_next, *fail, *nb_outputs;
+  uint32_t lmax;
 };
 
-struct ScanArgs {
-  const unsigned char *text;
-  uint64_t n;          /* symbols in the buffer */
-  uint64_t emit_from;  /* matches ending before this buffer index are not reported */
-  uint64_t pos_base;   /* reported end_pos = pos_base + buffer index */
+/* what turns a queued (position, state) into records; states in the numbering of the kernel
+ * that queued them.  The second half serves the continuations of the dense kernel. */
+struct EmitCtx {
+  const uint32_t *nb_outputs, *term_kw, *out_link, *depth;
   ACMRecord *records;
-  uint64_t capacity;
   unsigned long long *count;
-  /* range of this launch */
-  uint64_t range_begin, range_end; /* dense: tile indices; csr: symbol indices */
+  uint64_t capacity, pos_base;
+  const unsigned char *text;  /* segment */
+  const uint32_t *wrows;      /* continuation rows of every state: next | out flag << 15 | depth(next) << 16 */
+  const uint16_t *hotfail;    /* per state: nearest state on its failure chain whose row is in LDS */
+  uint32_t W, lo, span, n, emit_from;
 };
+
+/* one launch: a segment of the buffer, positions relative to its first symbol */
+struct Launch {
+  const unsigned char *text; /* first symbol of the segment */
+  uint32_t n;                /* symbols in the segment */
+  uint32_t emit_from;        /* matches ending before this index are not reported */
+  uint32_t range_begin, range_end; /* dense: tile indices; csr: symbol indices */
+};
+
+/* small uniform constants of the dense kernel */
+struct DenseK {
+  uint32_t W, rowbytes, lo, span;
+  uint32_t HD; /* states [0, HD): failure-resolved row in LDS */
+  uint32_t aux_off, queue_off, wub;
+};
+
+/* queue item, second word, when the dense kernel runs in continuation mode (16-bit states) */
+constexpr uint32_t IT_STATE = 0x7FFFu;
+constexpr uint32_t IT_CONT = 1u << 15;  /* walk on from this (rowless) state: see walk_continuation */
+constexpr uint32_t IT_SKIP_SHIFT = 16;  /* 12 bits: positions after pos that belong to the previous chunk */
+constexpr uint32_t IT_WARM = 1u << 28;  /* queued during a chunk's warm-up */
+constexpr uint32_t IT_OUT = 1u << 29;   /* report the outputs of the state itself at pos */
 
 /* ------------------------------------------------------------------ wave helpers */
 __device__ __forceinline__ uint32_t
 lane_id () {
   return __builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u));
+}
+
+__device__ __forceinline__ uint32_t
+uniform (uint32_t v) { /* tells the compiler the value is the same in every lane */
+  return __builtin_amdgcn_readfirstlane (v);
 }
 
 __device__ __forceinline__ uint32_t
@@ -88,167 +128,351 @@ wave_incl_scan (uint32_t v) {
   return v;
 }
 
-/* what the (out-of-line) queue expansion needs, passed by value in registers */
-struct EmitCtx {
-  const uint32_t *nb_outputs, *term_kw, *out_link, *depth;
-  ACMRecord *records;
-  unsigned long long *count;
-  uint64_t capacity, pos_base;
-};
-
-__device__ __forceinline__ EmitCtx
-make_emit_ctx (const DevTables &T, const ScanArgs &A) {
-  EmitCtx c;
-  c.nb_outputs = T.nb_outputs;
-  c.term_kw = T.term_kw;
-  c.out_link = T.out_link;
-  c.depth = T.depth;
-  c.records = A.records;
-  c.count = A.count;
-  c.capacity = A.capacity;
-  c.pos_base = A.pos_base;
-  return c;
+/* outputs of state st longer than `bound`, in acm_get_match index order (the state itself if
+ * terminal, then the chain of out_link: reference aho_corasick.c:459-466; lengths descend along
+ * the chain): counted, and written from offset o when WRITE */
+template <bool WRITE>
+__device__ __forceinline__ uint32_t
+put_outputs (const EmitCtx &E, uint32_t st, uint32_t pos, uint32_t bound, uint64_t o) {
+  uint32_t cnt = 0;
+  uint32_t t = E.term_kw[st] != NONE ? st : E.out_link[st];
+  while (t) {
+    const uint32_t len = E.depth[t];
+    if (len <= bound)
+      break;
+    if (WRITE && o + cnt < E.capacity) {
+      const uint64_t gp = E.pos_base + pos;
+      *reinterpret_cast<uint4 *> (&E.records[o + cnt]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), len, E.term_kw[t]);
+    }
+    cnt++;
+    t = E.out_link[t];
+  }
+  return cnt;
 }
 
-/* Expand the wave's queue into records: item = (buffer position, state with nb_outputs > 0).
- * Records of one position stay consecutive and in acm_get_match index order (the state itself if
- * terminal, then the chain of out_link: reference aho_corasick.c:459-466).  Must be called by
- * all 64 lanes. */
-template <bool COUNT_ONLY>
+/* what the walk of a continuation item found (it rarely finds more than one match position) */
+struct ContResult {
+  uint32_t cnt;      /* records in all */
+  uint32_t events;   /* positions with records */
+  uint32_t ev_pos, ev_state, ev_bound; /* the first of them */
+};
+
+/* Continuation item (dense kernel with 16-bit states): at `pos` the lane stepped into a state s
+ * that has no row in LDS and carried on from hotfail(s), the longest suffix state that has one.
+ * From there it still finds every match that starts within the last depth(hotfail(s)) symbols or
+ * later; the matches it can no longer see are the ones that started earlier and end after pos.
+ * They are recovered here: walk on from s itself through the HBM rows; after k more symbols every
+ * output longer than k + depth(hotfail(s)) is such a match; once the state's depth is <= that
+ * bound nothing more can be missing.  The walk stops at the end of the lane's chunk (later ends
+ * belong to the next chunk's owner, which finds them from its own warm-up).
+ * One dependent load per symbol: the row entry carries the next state, its output flag and its
+ * depth; the text byte of the following step is fetched alongside. */
+template <bool WRITE>
+__device__ __forceinline__ ContResult
+walk_continuation (const EmitCtx &E, uint2 it, uint64_t o) {
+  ContResult r = { 0, 0, 0, 0, 0 };
+  const uint32_t pos = it.x, st = it.y & IT_STATE;
+  const uint32_t dh = E.depth[E.hotfail[st]];
+  uint32_t own_begin = 0, chunk_end = (pos | (DENSE_C - 1)) + 1;
+  if (it.y & IT_WARM) {
+    own_begin = pos + ((it.y >> IT_SKIP_SHIFT) & 0xFFFu) + 1;
+    chunk_end = own_begin + DENSE_C;
+  }
+  if (own_begin < E.emit_from)
+    own_begin = E.emit_from;
+  const uint32_t lim = chunk_end < E.n ? chunk_end : E.n;
+  uint32_t s2 = st;
+  uint32_t byte = pos + 1 < lim ? E.text[pos + 1] : 0;
+  for (uint32_t k = 1; pos + k < lim; k++) {
+    const uint32_t p = pos + k;
+    const uint32_t ent = E.wrows[s2 * E.W + min (byte - E.lo, E.span)];
+    byte = p + 1 < lim ? E.text[p + 1] : 0;
+    s2 = ent & IT_STATE;
+    const uint32_t bound = k + dh;
+    if ((ent >> 16) <= bound)
+      break;
+    if ((ent & 0x8000u) && p >= own_begin) {
+      const uint32_t c = put_outputs<WRITE> (E, s2, p, bound, o + r.cnt);
+      if (c) {
+        if (!r.events) {
+          r.ev_pos = p;
+          r.ev_state = s2;
+          r.ev_bound = bound;
+        }
+        r.events++;
+        r.cnt += c;
+      }
+    }
+  }
+  return r;
+}
+
+/* number of records of one queue item (walks its continuation, remembering what it found) */
+template <bool CONT>
+__device__ __forceinline__ uint32_t
+item_count (const EmitCtx &E, bool valid, uint2 it, uint32_t &own_cnt, ContResult &r) {
+  const uint32_t st = CONT ? (it.y & IT_STATE) : it.y;
+  const bool own = valid && (!CONT || (it.y & IT_OUT));
+  own_cnt = own ? E.nb_outputs[st] : 0;
+  r = ContResult{ 0, 0, 0, 0, 0 };
+  if (CONT && valid && (it.y & IT_CONT))
+    r = walk_continuation<false> (E, it, 0);
+  return own_cnt + r.cnt;
+}
+
+/* writes them from offset o: the state's own outputs first, then the continuation's */
+template <bool CONT>
+__device__ __forceinline__ void
+item_write (const EmitCtx &E, uint2 it, uint32_t own_cnt, const ContResult &r, uint64_t o) {
+  const uint32_t st = CONT ? (it.y & IT_STATE) : it.y;
+  if (own_cnt)
+    (void)put_outputs<true> (E, st, it.x, 0, o);
+  if (r.events == 1)
+    (void)put_outputs<true> (E, r.ev_state, r.ev_pos, r.ev_bound, o + own_cnt);
+  else if (r.events > 1)
+    (void)walk_continuation<true> (E, it, o + own_cnt);
+}
+
+/* Expand a wave's queue into records: one global atomic per <= 64 items (wave prefix sum of the
+ * per-item counts), records of one item contiguous.  Must be called by all 64 lanes. */
+template <bool CONT, bool COUNT_ONLY>
 __device__ __noinline__ void
-flush_queue (EmitCtx E, const uint4 *queue, uint32_t n_items) {
+flush_queue (EmitCtx E, const uint2 *queue, uint32_t n_items) {
   const uint32_t lane = lane_id ();
   for (uint32_t base = 0; base < n_items; base += WAVE) {
     const uint32_t i = base + lane;
     const bool valid = i < n_items;
-    uint4 it = valid ? queue[i] : make_uint4 (0, 0, 0, 0);
-    const uint32_t st = it.z;
-    const uint32_t cnt = valid ? E.nb_outputs[st] : 0;
+    const uint2 it = valid ? queue[i] : make_uint2 (0, 0);
+    uint32_t own_cnt;
+    ContResult r;
+    const uint32_t cnt = item_count<CONT> (E, valid, it, own_cnt, r);
     const uint32_t incl = wave_incl_scan (cnt);
     const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
     unsigned long long gbase = 0;
     if (lane == 0 && total)
       gbase = atomicAdd (E.count, (unsigned long long)total);
     gbase = ((unsigned long long)__shfl ((uint32_t)(gbase >> 32), 0, WAVE) << 32) | __shfl ((uint32_t)gbase, 0, WAVE);
-    if (!COUNT_ONLY && cnt) {
-      const uint64_t pos = E.pos_base + (((uint64_t)it.y << 32) | it.x);
-      uint64_t o = gbase + (incl - cnt);
-      uint32_t t = E.term_kw[st] != NONE ? st : E.out_link[st];
-      while (t) {
-        if (o < E.capacity) {
-          uint4 rec = make_uint4 ((uint32_t)pos, (uint32_t)(pos >> 32), E.depth[t], E.term_kw[t]);
-          *reinterpret_cast<uint4 *> (&E.records[o]) = rec;
-        }
-        o++;
-        t = E.out_link[t];
-      }
+    if (!COUNT_ONLY && cnt)
+      item_write<CONT> (E, it, own_cnt, r, gbase + (incl - cnt));
+  }
+}
+
+/* Where a wave of the dense kernel parks its queue when it fills up: a private region of the
+ * plan's item buffer in HBM (plain coalesced stores, nothing to wait for).  expand_items_kernel
+ * turns the parked items into records afterwards with the whole chip's parallelism; a wave whose
+ * region is full expands in place instead (flush_queue), so nothing is ever dropped. */
+struct Spill {
+  uint2 *region;     /* this wave's region */
+  uint32_t capacity; /* items per region */
+  uint32_t fill;     /* items parked so far (wave-uniform) */
+};
+
+template <bool CONT, bool COUNT_ONLY>
+__device__ __forceinline__ void
+queue_drain (const EmitCtx &E, const uint2 *queue, uint32_t qn, Spill *sp, uint32_t lane) {
+  if (sp && sp->fill + qn <= sp->capacity) {
+    for (uint32_t i = lane; i < qn; i += WAVE)
+      sp->region[sp->fill + i] = queue[i];
+    sp->fill = uniform (sp->fill + qn);
+  } else
+    flush_queue<CONT, COUNT_ONLY> (E, queue, qn);
+}
+
+/* append one item per lane with `hit`; wave-uniform bookkeeping in qn */
+template <bool CONT, bool COUNT_ONLY>
+__device__ __forceinline__ void
+queue_push (const EmitCtx &E, uint2 *queue, uint32_t &qn, bool hit, uint32_t pos, uint32_t word, uint32_t lane,
+            Spill *sp = nullptr) {
+  const uint64_t m = __ballot (hit);
+  if (m) {
+    if (hit)
+      queue[qn + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos, word);
+    qn = uniform (qn + (uint32_t)__popcll (m));
+    if (qn > QCAP - WAVE) {
+      queue_drain<CONT, COUNT_ONLY> (E, queue, qn, sp, lane);
+      qn = 0;
     }
   }
 }
 
-/* ------------------------------------------------------------------ dense byte kernel */
+/* Expands the items parked by one workgroup of the dense kernel (its 16 waves' regions): 1024
+ * threads take 1024 items per round, a block-wide prefix sum of the per-item record counts gives
+ * every item its slot, and ONE global atomic per round reserves the records (a single counter
+ * sustains only ~90 atomics per microsecond, so they are kept to a few hundred per launch). */
+constexpr int EXPAND_THREADS = 1024;
+constexpr int EXPAND_REGIONS = DENSE_THREADS / WAVE;
+
+template <bool CONT, bool COUNT_ONLY>
+__global__ __launch_bounds__ (EXPAND_THREADS) void
+expand_items_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, const uint32_t *fill) {
+  __shared__ uint32_t s_off[EXPAND_REGIONS + 1];
+  __shared__ uint32_t s_wave[EXPAND_THREADS / WAVE];
+  __shared__ unsigned long long s_base;
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (int r = 0; r < EXPAND_REGIONS; r++) {
+      s_off[r] = acc;
+      acc += fill[blockIdx.x * EXPAND_REGIONS + r];
+    }
+    s_off[EXPAND_REGIONS] = acc;
+  }
+  __syncthreads ();
+  const uint32_t total = s_off[EXPAND_REGIONS];
+  for (uint32_t base = 0; base < total; base += EXPAND_THREADS) {
+    const uint32_t i = base + tid;
+    const bool valid = i < total;
+    uint2 it = make_uint2 (0, 0);
+    if (valid) {
+      uint32_t r = 0;
+#pragma unroll
+      for (int k = 1; k < EXPAND_REGIONS; k++)
+        r += s_off[k] <= i ? 1u : 0u;
+      it = items[(size_t)(blockIdx.x * EXPAND_REGIONS + r) * region_items + (i - s_off[r])];
+    }
+    uint32_t own_cnt;
+    ContResult res;
+    const uint32_t cnt = item_count<CONT> (E, valid, it, own_cnt, res);
+    const uint32_t incl = wave_incl_scan (cnt);
+    if (lane == WAVE - 1)
+      s_wave[wid] = incl;
+    __syncthreads ();
+    if (tid == 0) {
+      uint32_t acc = 0;
+      for (int k = 0; k < EXPAND_THREADS / WAVE; k++) {
+        const uint32_t v = s_wave[k];
+        s_wave[k] = acc;
+        acc += v;
+      }
+      s_base = acc ? atomicAdd (E.count, (unsigned long long)acc) : 0ull;
+    }
+    __syncthreads ();
+    if (!COUNT_ONLY && cnt)
+      item_write<CONT> (E, it, own_cnt, res, s_base + s_wave[wid] + (incl - cnt));
+    __syncthreads ();
+  }
+}
+
+/* ------------------------------------------------------------------ dense byte kernel
+ * ENTRY = uint16_t: "continuation mode".  LDS holds the rows of the HD shallowest states and, for
+ *   every other state s, hotfail(s).  A lane never sits in a rowless state: stepping into one
+ *   queues a continuation item and the lane carries on from hotfail(s) (walk_continuation explains why
+ *   nothing is lost).  The per-symbol path is: class, one ds_read_u16, compare, branch.
+ * ENTRY = uint32_t: "sticky mode" for dictionaries with more than 32768 states.  LDS holds the
+ *   rows of a breadth-first prefix; a lane in a deeper state is walked through the HBM rows on
+ *   the slow side until it comes back. */
 template <typename ENTRY> struct EntryTraits;
 template <> struct EntryTraits<uint16_t> {
   static constexpr uint32_t FLAG = 0x8000u;
+  static constexpr bool CONT = true;
 };
 template <> struct EntryTraits<uint32_t> {
   static constexpr uint32_t FLAG = 0x80000000u;
-};
-
-/* small uniform constants of the dense kernel, kept in SGPRs */
-struct DenseK {
-  uint32_t W, rowbytes, lo, span, HL;
+  static constexpr bool CONT = false;
 };
 
 /* per-wave walking state of the dense kernel */
 template <int S> struct Walk {
   uint32_t s[S];   /* current state of each stream */
-  uint64_t cs[S];  /* buffer index of the first byte of each stream's chunk */
   uint32_t qn;     /* queue fill (wave-uniform) */
-  uint32_t sticky; /* per lane: ~0 while one of its streams sits in a state whose row is not in LDS */
+  uint32_t sticky; /* sticky mode, per lane: ~0 while one of its streams sits in a rowless state */
+  Spill spill;
+  DIAG (unsigned long long d_slow_cycles = 0; unsigned long long d_slow_steps = 0;)
 };
 
+template <typename ENTRY>
 __device__ __forceinline__ uint32_t
-uniform (uint32_t v) { /* tells the compiler the value is the same in every lane */
-  return __builtin_amdgcn_readfirstlane (v);
+lds_row_entry (uint32_t state, uint32_t rowbytes, uint32_t cls) {
+  /* the rows start at LDS address 0 (no static LDS in this kernel): address the LDS by integer
+   * so that no base is added per lookup */
+  const uint32_t addr = __umul24 (state, rowbytes) + cls * (uint32_t)sizeof (ENTRY);
+  return *reinterpret_cast<const __attribute__ ((address_space (3))) ENTRY *> (addr);
 }
 
-/* Slow side of one step.  The whole wave comes here when some lane looked up an entry >= HL
- * (next state has outputs, or its row lives only in HBM) or some lane is currently in such a
- * cold state (its LDS lookup was meaningless and is redone from the HBM copy here). */
+/* where a step is: pos0 = position of stream 0's byte; in a warm-up block, `back` = distance from
+ * the block start to the chunk start and `skip` = positions between this byte and the chunk */
+struct StepAt {
+  uint32_t pos0, back, skip;
+  bool emit;
+};
+
+/* Slow side of one step: the whole wave comes here when some lane looked up an entry >= HD (next
+ * state has outputs and/or no row in LDS), or -- sticky mode -- sits in a rowless state. */
 template <typename ENTRY, int S, bool COUNT_ONLY>
 __device__ __forceinline__ void
-dense_step_slow (const DenseK &K, const EmitCtx &E, uint64_t emit_from, uint64_t emit_end, const ENTRY *__restrict__ gdense, uint4 *queue,
-                 Walk<S> &w, uint32_t (&e)[S], const uint32_t (&cls)[S], uint32_t j, bool emit, uint32_t lane) {
+dense_step_slow (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emit_end,
+                 const ENTRY *__restrict__ gdense, uint2 *queue, Walk<S> &w, uint32_t (&e)[S], const uint32_t (&cls)[S],
+                 const StepAt at, uint32_t lane) {
   constexpr uint32_t FLAG = EntryTraits<ENTRY>::FLAG;
   constexpr uint32_t IDMASK = FLAG - 1;
-  bool cold = false;
+  constexpr bool CONT = EntryTraits<ENTRY>::CONT;
+  bool rowless = false;
 #pragma unroll
   for (int q = 0; q < S; q++) {
-    if (w.s[q] >= K.HL)
+    const uint32_t pos = at.pos0 + (uint32_t)q * (WAVE * DENSE_C);
+    if (!CONT && w.s[q] >= K.HD) /* sticky mode: the LDS lookup was meaningless, redo it from HBM */
       e[q] = gdense[w.s[q] * K.W + cls[q]];
-    const uint32_t ns = e[q] & IDMASK;
-    const uint64_t pos = w.cs[q] + j;
-    const bool hit = emit && (e[q] & FLAG) && pos >= emit_from && pos < emit_end;
-    const uint64_t m = __ballot (hit);
-    if (m) {
-      if (hit)
-        queue[w.qn + __popcll (m & ((1ull << lane) - 1))] = make_uint4 ((uint32_t)pos, (uint32_t)(pos >> 32), ns, 0);
-      w.qn = uniform (w.qn + (uint32_t)__popcll (m));
-      if (w.qn > QCAP - WAVE) {
-        flush_queue<COUNT_ONLY> (E, queue, w.qn);
-        w.qn = 0;
-      }
+    uint32_t ns = e[q] & IDMASK;
+    const bool out = at.emit && (e[q] & FLAG) && pos >= emit_from && pos < emit_end;
+    if (CONT) {
+      /* a warm-up block that would start before the segment is walked on filler and discarded */
+      const bool real = at.emit || pos + at.skip + 1 >= at.back;
+      const bool deep = ns >= K.HD && real && pos < emit_end;
+      uint32_t word = ns | (deep ? IT_CONT : 0u) | (out ? IT_OUT : 0u);
+      if (!at.emit)
+        word |= IT_WARM | (at.skip << IT_SKIP_SHIFT);
+      queue_push<CONT, COUNT_ONLY> (E, queue, w.qn, out | deep, pos, word, lane, &w.spill);
+      if (ns >= K.HD)
+        ns = *reinterpret_cast<const __attribute__ ((address_space (3))) uint16_t *> (K.aux_off + (ns - K.HD) * 2u);
+    } else {
+      queue_push<CONT, COUNT_ONLY> (E, queue, w.qn, out, pos, ns, lane, &w.spill);
+      rowless |= ns >= K.HD;
     }
     w.s[q] = ns;
-    cold |= ns >= K.HL;
   }
-  w.sticky = cold ? ~0u : 0u;
+  if (!CONT)
+    w.sticky = rowless ? ~0u : 0u;
 }
 
-/* One step of all S streams of a lane: byte b[q] for stream q at chunk offset j.
- * Fast side per stream: class = min(byte - lo, span); one ds_read_u16/b32 at
- * row(state) + class; all streams share one compare-and-branch. */
+/* One step of all S streams of a lane: byte b[q] for stream q.
+ * Fast side per stream: class = min(byte - lo, span); one ds_read at row(state) + class; all
+ * streams share one compare-and-branch. */
 template <typename ENTRY, int S, bool COUNT_ONLY>
 __device__ __forceinline__ void
-dense_step (const DenseK &K, const EmitCtx &E, uint64_t emit_from, uint64_t emit_end, const unsigned char *lds,
-            const ENTRY *__restrict__ gdense, uint4 *queue, Walk<S> &w, const uint32_t (&b)[S], uint32_t j, bool emit,
-            uint32_t lane) {
+dense_step (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emit_end, const ENTRY *__restrict__ gdense,
+            uint2 *queue, Walk<S> &w, const uint32_t (&b)[S], const StepAt at, uint32_t lane) {
   uint32_t cls[S], e[S];
 #pragma unroll
   for (int q = 0; q < S; q++) {
     cls[q] = min (b[q] - K.lo, K.span);
-    /* a cold lane reads past the staged rows: LDS returns 0 for out-of-range addresses and the
-     * value is replaced on the slow side */
-    const uint32_t addr = __umul24 (w.s[q], K.rowbytes) + cls[q] * (uint32_t)sizeof (ENTRY);
-    /* the staged rows start at LDS address 0 (no static LDS in this kernel): address the LDS
-     * by integer so that no base is added per lookup */
-    e[q] = *reinterpret_cast<const __attribute__ ((address_space (3))) ENTRY *> (addr);
+    e[q] = lds_row_entry<ENTRY> (w.s[q], K.rowbytes, cls[q]);
   }
-  uint32_t emax = w.sticky;
+  uint32_t emax = EntryTraits<ENTRY>::CONT ? 0u : w.sticky;
 #pragma unroll
   for (int q = 0; q < S; q++)
     emax = max (emax, e[q]);
-  if (__builtin_expect (__ballot (emax >= K.HL) != 0, 0))
-    dense_step_slow<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, e, cls, j, emit, lane);
-  else {
+  if (__builtin_expect (__ballot (emax >= K.HD) != 0, 0)) {
+    DIAG (const unsigned long long t0_ = __builtin_readcyclecounter ();)
+    dense_step_slow<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, e, cls, at, lane);
+    DIAG (w.d_slow_cycles += __builtin_readcyclecounter () - t0_; w.d_slow_steps++;)
+  } else {
 #pragma unroll
     for (int q = 0; q < S; q++)
       w.s[q] = e[q];
   }
 }
 
-/* 16 steps over one 16-byte block per stream */
+/* 16 steps over one 16-byte block per stream; at = where the block's first byte is */
 template <typename ENTRY, int S, bool COUNT_ONLY>
 __device__ __forceinline__ void
-dense_block (const DenseK &K, const EmitCtx &E, uint64_t emit_from, uint64_t emit_end, const unsigned char *tab,
-             const ENTRY *__restrict__ gdense, uint4 *queue, Walk<S> &w, const uint4 (&blk)[S], uint32_t j0, bool emit,
-             uint32_t lane) {
+dense_block (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emit_end, const ENTRY *__restrict__ gdense,
+             uint2 *queue, Walk<S> &w, const uint4 (&blk)[S], const StepAt at, uint32_t lane) {
 #define ACM_BYTE(COMP, SH, J)                                                                      \
   {                                                                                                \
     uint32_t b_[S];                                                                                \
     _Pragma ("unroll") for (int q = 0; q < S; q++) b_[q] = (blk[q].COMP >> (SH)) & 0xffu;          \
-    dense_step<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, tab, gdense, queue, w, b_, j0 + (J), emit, lane); \
+    const StepAt at_ = { at.pos0 + (J), at.back, at.skip - (J), at.emit };                         \
+    dense_step<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, b_, at_, lane); \
   }
 #define ACM_WORD(COMP, J)                                                                          \
   ACM_BYTE (COMP, 0, (J) + 0) ACM_BYTE (COMP, 8, (J) + 1) ACM_BYTE (COMP, 16, (J) + 2) ACM_BYTE (COMP, 24, (J) + 3)
@@ -260,111 +484,115 @@ dense_block (const DenseK &K, const EmitCtx &E, uint64_t emit_from, uint64_t emi
 /* compile-time loop over the C/16 blocks of a chunk (keeps the text registers statically indexed) */
 template <typename ENTRY, int S, bool COUNT_ONLY, int K0, int KN> struct BlockLoop {
   static __device__ __forceinline__ void
-  run (const DenseK &K, const EmitCtx &E, uint64_t emit_from, uint64_t emit_end, const unsigned char *tab,
-       const ENTRY *__restrict__ gdense, uint4 *queue, Walk<S> &w, const uint4 (&d)[KN][S], uint32_t lane) {
-    dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, tab, gdense, queue, w, d[K0], 16 * K0, true, lane);
-    BlockLoop<ENTRY, S, COUNT_ONLY, K0 + 1, KN>::run (K, E, emit_from, emit_end, tab, gdense, queue, w, d, lane);
+  run (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emit_end, const ENTRY *__restrict__ gdense,
+       uint2 *queue, Walk<S> &w, const uint4 (&d)[KN][S], uint32_t pos0, uint32_t lane) {
+    const StepAt at = { pos0 + 16 * K0, 0, 0, true };
+    dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[K0], at, lane);
+    BlockLoop<ENTRY, S, COUNT_ONLY, K0 + 1, KN>::run (K, E, emit_from, emit_end, gdense, queue, w, d, pos0, lane);
   }
 };
 template <typename ENTRY, int S, bool COUNT_ONLY, int KN> struct BlockLoop<ENTRY, S, COUNT_ONLY, KN, KN> {
   static __device__ __forceinline__ void
-  run (const DenseK &, const EmitCtx &, uint64_t, uint64_t, const unsigned char *, const ENTRY *__restrict__, uint4 *,
-       Walk<S> &, const uint4 (&)[KN][S], uint32_t) {}
+  run (const DenseK &, const EmitCtx &, uint32_t, uint32_t, const ENTRY *__restrict__, uint2 *, Walk<S> &,
+       const uint4 (&)[KN][S], uint32_t, uint32_t) {}
 };
 
-/* Tiles [range_begin, range_end) of 64*S*C bytes cover the whole buffer, the last one possibly
+/* Tiles [range_begin, range_end) of 64*S*C bytes cover the whole segment, the last one possibly
  * ragged.  16-byte loads are clamped to the last block that holds a valid byte (an aligned
  * 16-byte block never straddles a page, so it cannot fault); what a lane walks beyond the end of
- * the buffer is never reported (emit window [emit_from, n)). */
+ * the segment is never reported (emit window [emit_from, n)).
+ * LDS image: [HD rows][continuation mode: hotfail of every other state, 2 B each][16 queues]. */
 template <typename ENTRY, int C, int S, bool COUNT_ONLY>
 __global__ __launch_bounds__ (DENSE_THREADS) void
-scan_dense_kernel (DevTables T, ScanArgs A, const ENTRY *__restrict__ gdense, const unsigned char *__restrict__ text,
-                   uint32_t queue_off) {
+scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gdense, const uint4 *__restrict__ lds_image,
+                   uint32_t lds_image_bytes, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
+                   uint32_t *fill) {
   extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
-  const unsigned char *tab = smem;
   constexpr uint32_t TILE = WAVE * S * C;
   constexpr int NB = C / 16;
+  constexpr bool CONT = EntryTraits<ENTRY>::CONT;
 
-  /* stage the hottest rows: a straight 16-byte-per-lane copy (the source is padded to 16 bytes) */
+  /* stage rows (+ hotfail): a straight 16-byte-per-lane copy of the prebuilt image */
   {
-    const uint32_t bytes = T.lds_rows * T.width * (uint32_t)sizeof (ENTRY);
-    const uint4 *src = reinterpret_cast<const uint4 *> (gdense);
     uint4 *dst = reinterpret_cast<uint4 *> (smem);
-    for (uint32_t i = threadIdx.x; i < (bytes + 15) / 16; i += blockDim.x)
-      dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < lds_image_bytes / 16; i += blockDim.x)
+      dst[i] = lds_image[i];
   }
   __syncthreads ();
 
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint32_t wib = uniform (threadIdx.x / WAVE);
-  uint4 *queue = reinterpret_cast<uint4 *> (smem + queue_off) + wib * QCAP;
+  uint2 *queue = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
   const uint32_t waves_per_block = blockDim.x / WAVE;
-  const uint64_t wave = (uint64_t)blockIdx.x * waves_per_block + wib;
-  const uint64_t nwaves = (uint64_t)gridDim.x * waves_per_block;
-  const uint32_t wub = (T.lmax > 1 ? (T.lmax - 1 + 15) / 16 : 0); /* warm-up blocks of 16 bytes */
-  const DenseK K = { T.width, T.width * (uint32_t)sizeof (ENTRY), T.lo, T.span, T.lds_rows };
-  const EmitCtx E = make_emit_ctx (T, A);
-  const uint64_t emit_from = A.emit_from, emit_end = A.n;
-  const uint64_t last_block = (A.n - 1) & ~15ull; /* byte offset of the last 16-byte block with a valid byte */
+  const uint32_t wave = blockIdx.x * waves_per_block + wib;
+  const uint32_t nwaves = gridDim.x * waves_per_block;
+  const uint32_t emit_from = A.emit_from, emit_end = A.n;
+  const uint32_t last_block = (A.n - 1) & ~15u; /* byte offset of the last 16-byte block with a valid byte */
 
   Walk<S> w;
   w.qn = 0;
   w.sticky = 0;
+  w.spill.region = items + (size_t)wave * region_items;
+  w.spill.capacity = items ? region_items : 0;
+  w.spill.fill = 0;
+  DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_text = 0, d_tiles = 0;)
 
-  for (uint64_t tile = A.range_begin + wave; tile < A.range_end; tile += nwaves) {
-    const uint64_t tbase = tile * TILE;
+  for (uint32_t tile = A.range_begin + wave; tile < A.range_end; tile += nwaves) {
+    const uint32_t tbase = tile * TILE;
+    DIAG (const unsigned long long d_tl = __builtin_readcyclecounter ();)
+    const uint32_t pos0 = tbase + lane * C; /* first byte of this lane's stream 0 */
     uint4 d[NB][S];
 #pragma unroll
     for (int q = 0; q < S; q++) {
-      w.cs[q] = tbase + (uint64_t)(q * WAVE + lane) * C;
 #pragma unroll
       for (int k = 0; k < NB; k++) {
-        const uint64_t off = w.cs[q] + 16 * k;
+        const uint32_t off = pos0 + q * (WAVE * C) + 16 * k;
         d[k][q] = *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
       }
       w.s[q] = 0;
     }
     w.sticky = 0;
-    /* pull the wave's next tile towards L2 while this one is walked: one dword per lane-stream
-     * touches every 64-byte half line of it */
-    uint32_t touch[S];
-    {
-      const uint64_t nbase = tbase + nwaves * TILE;
-#pragma unroll
-      for (int q = 0; q < S; q++) {
-        const uint64_t off = nbase + (uint64_t)(q * WAVE + lane) * C;
-        touch[q] = *reinterpret_cast<const uint32_t *> (text + (off < last_block ? off : last_block));
-      }
-    }
+    DIAG (asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); d_text += __builtin_readcyclecounter () - d_tl; d_tiles++;)
     /* warm-up: wub 16-byte blocks before each chunk, walked from the root without reporting
      * (matches ending there belong to the previous chunk's owner).  A chunk closer than that to
-     * the start of the buffer starts from the root at its first in-range block instead. */
-    for (uint32_t b = wub; b >= 1; b--) {
+     * the start of the segment starts from the root at its first in-range block instead. */
+    for (uint32_t b = K.wub; b >= 1; b--) {
       uint4 pre[S];
+      const uint32_t back = 16u * b;
 #pragma unroll
       for (int q = 0; q < S; q++) {
-        const uint64_t back = 16ull * b;
-        const uint64_t off = w.cs[q] >= back ? w.cs[q] - back : 0;
+        const uint32_t cs = pos0 + q * (WAVE * C);
+        const uint32_t off = cs >= back ? cs - back : 0;
         pre[q] = *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
       }
-      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, tab, gdense, queue, w, pre, 0, false, lane);
+      const StepAt at = { pos0 - back, back, back - 1, false };
+      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, pre, at, lane);
 #pragma unroll
       for (int q = 0; q < S; q++)
-        if (w.cs[q] < 16ull * b)
+        if (pos0 + q * (WAVE * C) < back)
           w.s[q] = 0;
     }
-    BlockLoop<ENTRY, S, COUNT_ONLY, 0, NB>::run (K, E, emit_from, emit_end, tab, gdense, queue, w, d, lane);
-#pragma unroll
-    for (int q = 0; q < S; q++)
-      asm volatile("" ::"v"(touch[q])); /* keeps the prefetch loads alive; they landed long ago */
+    BlockLoop<ENTRY, S, COUNT_ONLY, 0, NB>::run (K, E, emit_from, emit_end, gdense, queue, w, d, pos0, lane);
   }
-  flush_queue<COUNT_ONLY> (E, queue, w.qn);
+  if (w.qn)
+    queue_drain<CONT, COUNT_ONLY> (E, queue, w.qn, &w.spill, lane);
+  if (lane == 0 && fill)
+    fill[wave] = w.spill.fill;
+  DIAG (if (lane == 0 && wave < 8192) {
+    unsigned long long *o = g_acm_diag[wave];
+    o[0] = __builtin_readcyclecounter () - d_t0;
+    o[1] = 0;
+    o[2] = w.spill.fill;
+    o[3] = w.d_slow_steps;
+    o[4] = w.d_slow_cycles;
+    o[5] = d_text;
+    o[6] = d_tiles;
+  })
 }
 
 /* ------------------------------------------------------------------ CSR kernel (any width) */
-template <typename SYM>
 __device__ __forceinline__ uint32_t
-csr_step (const DevTables &T, uint32_t s, uint32_t c) {
+csr_step (const CsrTables &T, uint32_t s, uint32_t c) {
   for (;;) {
     uint32_t b = T.row_ptr[s], e = T.row_ptr[s + 1];
     if (e - b > 8) { /* rows are sorted by numeric symbol value */
@@ -389,58 +617,48 @@ csr_step (const DevTables &T, uint32_t s, uint32_t c) {
 }
 
 /* One lane walks `chunk` symbols of [range_begin, range_end), restarting from the root lmax-1
- * symbols earlier (or at buffer index 0).  blockDim.x == 64: one wave per block, its queue in
- * static LDS. */
+ * symbols earlier (or at index 0 of the segment).  blockDim.x == 64: one wave per block. */
 template <typename SYM, bool COUNT_ONLY>
 __global__ __launch_bounds__ (WAVE) void
-scan_csr_kernel (DevTables T, ScanArgs A, uint32_t chunk) {
-  __shared__ uint4 queue[QCAP];
+scan_csr_kernel (CsrTables T, EmitCtx E, Launch A, uint32_t chunk) {
+  __shared__ uint2 queue[QCAP];
   const uint32_t lane = threadIdx.x;
   const SYM *text = reinterpret_cast<const SYM *> (A.text);
-  const uint64_t nchunks = (A.range_end - A.range_begin + chunk - 1) / chunk;
-  const uint64_t rounds = (nchunks + (uint64_t)gridDim.x * WAVE - 1) / ((uint64_t)gridDim.x * WAVE);
-  const uint64_t warm = T.lmax > 1 ? T.lmax - 1 : 0;
+  const uint32_t nchunks = (A.range_end - A.range_begin + chunk - 1) / chunk;
+  const uint32_t per_round = gridDim.x * WAVE;
+  const uint32_t rounds = (nchunks + per_round - 1) / per_round;
+  const uint32_t warm = T.lmax > 1 ? T.lmax - 1 : 0;
   uint32_t qn = 0;
-  const EmitCtx E = make_emit_ctx (T, A);
-  for (uint64_t r = 0; r < rounds; r++) {
-    const uint64_t ck = (r * gridDim.x + blockIdx.x) * WAVE + lane;
-    uint64_t begin = A.range_end, end = A.range_end, i = A.range_end;
+  for (uint32_t r = 0; r < rounds; r++) {
+    const uint32_t ck = (r * gridDim.x + blockIdx.x) * WAVE + lane;
+    uint32_t begin = A.range_end, end = A.range_end, i = A.range_end;
     if (ck < nchunks) {
       begin = A.range_begin + ck * chunk;
-      end = begin + chunk < A.range_end ? begin + chunk : A.range_end;
+      end = A.range_end - begin > chunk ? begin + chunk : A.range_end;
       i = begin > warm ? begin - warm : 0;
     }
     uint32_t s = 0;
     /* all lanes iterate together so that the queue stays a wave-level structure */
-    const uint64_t steps_max = chunk + warm;
-    for (uint64_t k = 0; k < steps_max; k++, i++) {
+    const uint32_t steps_max = chunk + warm;
+    for (uint32_t k = 0; k < steps_max; k++, i++) {
       bool hit = false;
       if (i < end) {
-        s = csr_step<SYM> (T, s, (uint32_t)text[i]);
+        s = csr_step (T, s, (uint32_t)text[i]);
         hit = i >= begin && i >= A.emit_from && T.nb_outputs[s] != 0;
       }
-      const uint64_t m = __ballot (hit);
-      if (m) {
-        if (hit)
-          queue[qn + __popcll (m & ((1ull << lane) - 1))] = make_uint4 ((uint32_t)i, (uint32_t)(i >> 32), s, 0);
-        qn += (uint32_t)__popcll (m);
-        if (qn > QCAP - WAVE) {
-          flush_queue<COUNT_ONLY> (E, queue, qn);
-          qn = 0;
-        }
-      }
+      queue_push<false, COUNT_ONLY> (E, queue, qn, hit, i, s, lane);
     }
   }
-  flush_queue<COUNT_ONLY> (E, queue, qn);
+  flush_queue<false, COUNT_ONLY> (E, queue, qn);
 }
 
 /* ------------------------------------------------------------------ sort keys */
 __global__ void
-make_keys_kernel (const ACMRecord *rec, uint64_t n, uint64_t pos_min, uint32_t len_bits, uint64_t *keys) {
+make_keys_kernel (const ACMRecord *rec, uint64_t n, uint32_t len_bits, uint64_t *keys) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const uint64_t lmask = (1ull << len_bits) - 1;
-    keys[i] = ((rec[i].end_pos - pos_min) << len_bits) | (lmask - (rec[i].length & lmask));
+    keys[i] = (rec[i].end_pos << len_bits) | (lmask - (rec[i].length & lmask));
   }
 }
 
@@ -459,9 +677,7 @@ splitmix64 (uint64_t x) {
 
 template <typename SYM>
 __global__ void
-synth_text_kernel (SYM *text, uint64_t n, uint64_t gbegin, uint64_t n_total_hint, uint32_t vocab, const SYM *kw, const uint32_t *kw_off,
-                   uint32_t n_kw) {
-  (void)n_total_hint;
+synth_text_kernel (SYM *text, uint64_t n, uint64_t gbegin, uint32_t vocab, const SYM *kw, const uint32_t *kw_off, uint32_t n_kw) {
   constexpr uint64_t P = 4096;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; li < n; li += stride) {
@@ -485,11 +701,24 @@ synth_text_kernel (SYM *text, uint64_t n, uint64_t gbegin, uint64_t n_total_hint
 struct ACMPlan {
   int device = 0;
   ACMFlatInfo finfo{};
-  DevTables T{};
   ACMPlanInfo info{};
   void *blob = nullptr; /* one device allocation holding every table */
   size_t blob_bytes = 0;
-  uint32_t queue_off = 0;
+  /* CSR kernel (breadth-first numbering) */
+  CsrTables csr{};
+  const uint32_t *c_term_kw = nullptr, *c_out_link = nullptr, *c_depth = nullptr;
+  /* dense kernel (breadth-first numbering too: the LDS rows are a breadth-first prefix) */
+  DenseK K{};
+  const void *d_dense = nullptr;     /* failure-resolved rows of every state */
+  const void *d_lds_image = nullptr; /* what every workgroup copies into LDS */
+  const uint32_t *d_wrows = nullptr;
+  const uint16_t *d_hotfail = nullptr;
+  uint32_t lds_image_bytes = 0;
+  uint32_t entry_bytes = 0, streams = 2;
+  /* item buffer of the dense kernel: regions x region_items items of 8 B, one region per wave */
+  void *d_items = nullptr;
+  uint32_t *d_fill = nullptr;
+  uint32_t regions = 0, region_items = 0;
   uint64_t generation = 0; /* for the machine-cached plan */
   int cu_count = 0;
   /* timing */
@@ -524,25 +753,30 @@ acm_gpu_device_count (void) {
 
 namespace {
 
-template <typename T>
 size_t
-blob_reserve (size_t &cursor, size_t count) {
+blob_reserve (size_t &cursor, size_t bytes) {
   cursor = (cursor + 255) & ~(size_t)255;
   size_t at = cursor;
-  cursor += count * sizeof (T);
+  cursor += bytes;
   return at;
 }
 
-using DenseKernel16 = void (*) (DevTables, ScanArgs, const uint16_t *, const unsigned char *, uint32_t);
-using DenseKernel32 = void (*) (DevTables, ScanArgs, const uint32_t *, const unsigned char *, uint32_t);
-
-DenseKernel16
-dense_kernel16 (bool count_only) {
-  return count_only ? scan_dense_kernel<uint16_t, DENSE_C, DENSE_S, true> : scan_dense_kernel<uint16_t, DENSE_C, DENSE_S, false>;
+template <typename ENTRY, int S, bool CO>
+const void *
+dense_fn () {
+  return reinterpret_cast<const void *> (&scan_dense_kernel<ENTRY, DENSE_C, S, CO>);
 }
-DenseKernel32
-dense_kernel32 (bool count_only) {
-  return count_only ? scan_dense_kernel<uint32_t, DENSE_C, DENSE_S, true> : scan_dense_kernel<uint32_t, DENSE_C, DENSE_S, false>;
+
+const void *
+dense_kernel_ptr (uint32_t entry_bytes, uint32_t streams, bool count_only) {
+  if (entry_bytes == 2) {
+    if (streams == 4)
+      return count_only ? dense_fn<uint16_t, 4, true> () : dense_fn<uint16_t, 4, false> ();
+    return count_only ? dense_fn<uint16_t, 2, true> () : dense_fn<uint16_t, 2, false> ();
+  }
+  if (streams == 4)
+    return count_only ? dense_fn<uint32_t, 4, true> () : dense_fn<uint32_t, 4, false> ();
+  return count_only ? dense_fn<uint32_t, 2, true> () : dense_fn<uint32_t, 2, false> ();
 }
 
 void
@@ -578,37 +812,59 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   p->device = device;
   p->finfo = fi;
   p->cu_count = prop.multiProcessorCount;
+  if (const char *e = getenv ("ACM_GPU_STREAMS"))
+    p->streams = atoi (e) == 4 ? 4 : 2;
 
-  /* dense rows for byte alphabets whenever the whole DFA fits comfortably in HBM */
+  /* failure-resolved rows for byte alphabets whenever the whole DFA fits comfortably in HBM */
   const uint32_t n = fi.n_states;
-  uint32_t entry_bytes = n <= 32768 ? 2 : 4;
-  bool dense = fi.sym_bytes == 1 && fi.n_edges > 0 && (uint64_t)n * fi.width < (1ull << 31) &&
-               (uint64_t)n * fi.width * entry_bytes <= (8ull << 30);
-  const uint32_t nwaves_blk = DENSE_THREADS / WAVE;
-  const uint32_t queue_bytes = nwaves_blk * QCAP * 16;
-  uint32_t lds_rows = 0, table_lds = 0;
+  const uint32_t entry_bytes = n <= 32768 ? 2 : 4;
+  const bool dense = fi.sym_bytes == 1 && fi.n_edges > 0 && (uint64_t)n * fi.width < (1ull << 31) &&
+                     (uint64_t)n * fi.width * entry_bytes <= (8ull << 30) && fi.lmax >= 1 && fi.lmax - 1 <= 16u * 255;
+  const bool cont = dense && entry_bytes == 2; /* continuation mode, see scan_dense_kernel */
+  const uint32_t rowbytes = fi.width * entry_bytes;
+  const uint32_t queue_bytes = (DENSE_THREADS / WAVE) * QCAP * 8;
+
+  /* ---- LDS budget: rows of a breadth-first prefix [0, HD); continuation mode also keeps
+   *      hotfail(s) (2 bytes) for every other state */
+  uint32_t HD = 0;
   if (dense) {
     const uint32_t lds_total = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
-    const uint32_t budget = lds_total - queue_bytes - 1024;
-    const uint32_t row_bytes = fi.width * entry_bytes;
-    lds_rows = budget / row_bytes;
-    if (lds_rows > n)
-      lds_rows = n;
-    /* keep the LDS-resident prefix below the flag bit */
-    table_lds = (lds_rows * row_bytes + 15) & ~15u;
+    const uint32_t budget = lds_total - queue_bytes - 512;
+    if (cont) {
+      /* HD * rowbytes + (n - HD) * 2 <= budget */
+      const uint64_t fixed = (uint64_t)n * 2;
+      HD = fixed >= budget ? 1 : (uint32_t)((budget - fixed) / (rowbytes - 2));
+    } else
+      HD = budget / rowbytes;
+    if (HD > n)
+      HD = n;
+    if (HD < 1)
+      HD = 1;
+  }
+  std::vector<uint16_t> hotfail;
+  if (cont) {
+    hotfail.resize (n);
+    for (uint32_t s = 0; s < n; s++) /* f(s) < s: one pass in breadth-first order */
+      hotfail[s] = (uint16_t)(s < HD ? s : hotfail[fv.fail[s]]);
   }
 
+  /* ---- device blob layout */
   size_t cur = 0;
-  const size_t o_row = blob_reserve<uint32_t> (cur, (size_t)n + 1);
-  const size_t o_sym = blob_reserve<uint32_t> (cur, fi.n_edges ? fi.n_edges : 1);
-  const size_t o_next = blob_reserve<uint32_t> (cur, fi.n_edges ? fi.n_edges : 1);
-  const size_t o_fail = blob_reserve<uint32_t> (cur, n);
-  const size_t o_depth = blob_reserve<uint32_t> (cur, n);
-  const size_t o_nbo = blob_reserve<uint32_t> (cur, n);
-  const size_t o_term = blob_reserve<uint32_t> (cur, n);
-  const size_t o_link = blob_reserve<uint32_t> (cur, n);
-  const size_t dense_bytes = dense ? (size_t)n * fi.width * entry_bytes : 0;
-  const size_t o_dense = blob_reserve<unsigned char> (cur, dense_bytes + 16);
+  const size_t o_row = blob_reserve (cur, ((size_t)n + 1) * 4);
+  const size_t o_sym = blob_reserve (cur, (size_t)(fi.n_edges ? fi.n_edges : 1) * 4);
+  const size_t o_next = blob_reserve (cur, (size_t)(fi.n_edges ? fi.n_edges : 1) * 4);
+  const size_t o_fail = blob_reserve (cur, (size_t)n * 4);
+  const size_t o_cnbo = blob_reserve (cur, (size_t)n * 4);
+  const size_t o_cterm = blob_reserve (cur, (size_t)n * 4);
+  const size_t o_clink = blob_reserve (cur, (size_t)n * 4);
+  const size_t o_cdepth = blob_reserve (cur, (size_t)n * 4);
+  const size_t dense_bytes = dense ? (size_t)n * rowbytes : 0;
+  const size_t o_dense = blob_reserve (cur, dense_bytes + 16);
+  const size_t o_hotfail = blob_reserve (cur, cont ? (size_t)n * 2 : 0);
+  const size_t o_wrows = blob_reserve (cur, cont ? (size_t)n * fi.width * 4 : 0);
+  const uint32_t rows_lds = dense ? ((HD * rowbytes + 15) & ~15u) : 0;
+  const uint32_t image_bytes = dense ? ((rows_lds + (cont ? (n - HD) * 2 : 0) + 15) & ~15u) : 0;
+  const size_t o_image = blob_reserve (cur, image_bytes + 16);
   p->blob_bytes = cur;
 
   std::vector<unsigned char> host (cur, 0);
@@ -616,15 +872,25 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   memcpy (&host[o_sym], fv.edge_sym, (size_t)fi.n_edges * 4);
   memcpy (&host[o_next], fv.edge_next, (size_t)fi.n_edges * 4);
   memcpy (&host[o_fail], fv.fail, (size_t)n * 4);
-  memcpy (&host[o_depth], fv.depth, (size_t)n * 4);
-  memcpy (&host[o_nbo], fv.nb_outputs, (size_t)n * 4);
-  memcpy (&host[o_term], fv.term_kw, (size_t)n * 4);
-  memcpy (&host[o_link], fv.out_link, (size_t)n * 4);
+  memcpy (&host[o_cnbo], fv.nb_outputs, (size_t)n * 4);
+  memcpy (&host[o_cterm], fv.term_kw, (size_t)n * 4);
+  memcpy (&host[o_clink], fv.out_link, (size_t)n * 4);
+  memcpy (&host[o_cdepth], fv.depth, (size_t)n * 4);
   if (dense) {
     int rc = acm_flat_dense_rows (flat, n, entry_bytes, &host[o_dense]);
     if (rc) {
       delete p;
       return rc;
+    }
+    /* LDS image: the first HD rows, then hotfail of the states [HD, n) */
+    memcpy (&host[o_image], &host[o_dense], (size_t)HD * rowbytes);
+    if (cont) {
+      const uint16_t *r16 = reinterpret_cast<const uint16_t *> (&host[o_dense]);
+      uint32_t *wr = reinterpret_cast<uint32_t *> (&host[o_wrows]);
+      for (size_t i = 0; i < (size_t)n * fi.width; i++)
+        wr[i] = r16[i] | (fv.depth[r16[i] & 0x7FFFu] << 16);
+      memcpy (&host[o_hotfail], hotfail.data (), (size_t)n * 2);
+      memcpy (&host[o_image + rows_lds], hotfail.data () + HD, (size_t)(n - HD) * 2);
     }
   }
   if (hipMalloc (&p->blob, cur) != hipSuccess) {
@@ -637,46 +903,53 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     return ACM_GPU_E_HIP;
   }
   unsigned char *b = static_cast<unsigned char *> (p->blob);
-  DevTables &T = p->T;
-  T.row_ptr = reinterpret_cast<uint32_t *> (b + o_row);
-  T.edge_sym = reinterpret_cast<uint32_t *> (b + o_sym);
-  T.edge_next = reinterpret_cast<uint32_t *> (b + o_next);
-  T.fail = reinterpret_cast<uint32_t *> (b + o_fail);
-  T.depth = reinterpret_cast<uint32_t *> (b + o_depth);
-  T.nb_outputs = reinterpret_cast<uint32_t *> (b + o_nbo);
-  T.term_kw = reinterpret_cast<uint32_t *> (b + o_term);
-  T.out_link = reinterpret_cast<uint32_t *> (b + o_link);
-  T.dense = dense ? b + o_dense : nullptr;
-  T.n_states = n;
-  T.width = fi.width;
-  T.lo = fi.alpha_lo;
-  T.span = fi.alpha_span;
-  T.dense_rows = dense ? n : 0;
-  T.lds_rows = lds_rows;
-  T.lmax = fi.lmax;
-  T.entry_bytes = entry_bytes;
-  p->queue_off = table_lds;
+  auto u32p = [&] (size_t off) { return reinterpret_cast<const uint32_t *> (b + off); };
+  p->csr.row_ptr = u32p (o_row);
+  p->csr.edge_sym = u32p (o_sym);
+  p->csr.edge_next = u32p (o_next);
+  p->csr.fail = u32p (o_fail);
+  p->csr.nb_outputs = u32p (o_cnbo);
+  p->csr.lmax = fi.lmax;
+  p->c_term_kw = u32p (o_cterm);
+  p->c_out_link = u32p (o_clink);
+  p->c_depth = u32p (o_cdepth);
+  p->entry_bytes = entry_bytes;
+  if (dense) {
+    p->d_dense = b + o_dense;
+    p->d_lds_image = b + o_image;
+    p->d_hotfail = cont ? reinterpret_cast<const uint16_t *> (b + o_hotfail) : nullptr;
+    p->d_wrows = cont ? reinterpret_cast<const uint32_t *> (b + o_wrows) : nullptr;
+    p->lds_image_bytes = image_bytes;
+    DenseK &K = p->K;
+    K.W = fi.width;
+    K.rowbytes = rowbytes;
+    K.lo = fi.alpha_lo;
+    K.span = fi.alpha_span;
+    K.HD = HD;
+    K.aux_off = rows_lds;
+    K.queue_off = image_bytes;
+    K.wub = fi.lmax > 1 ? (fi.lmax - 1 + 15) / 16 : 0;
+  }
 
   ACMPlanInfo &I = p->info;
   I.device = device;
   I.kernel = dense ? 1 : 2;
   I.entry_bytes = dense ? entry_bytes : 0;
   I.width = fi.width;
-  I.dense_rows = T.dense_rows;
-  I.lds_rows = lds_rows;
-  I.lds_bytes = dense ? table_lds + queue_bytes : QCAP * 16;
+  I.dense_rows = dense ? n : 0;
+  I.lds_rows = HD;
+  I.lds_hotfail = cont ? n - HD : 0;
+  I.lds_bytes = dense ? image_bytes + queue_bytes : QCAP * 8;
   I.block_threads = dense ? DENSE_THREADS : WAVE;
   I.grid_blocks = dense ? (uint32_t)p->cu_count : (uint32_t)p->cu_count * 16;
   I.chunk_bytes = DENSE_C;
-  I.streams = DENSE_S;
+  I.streams = p->streams;
   I.table_bytes = cur;
 
   if (dense) {
-    for (int co = 0; co < 2; co++) {
-      const void *fn = entry_bytes == 2 ? reinterpret_cast<const void *> (dense_kernel16 (co != 0))
-                                        : reinterpret_cast<const void *> (dense_kernel32 (co != 0));
-      HIP_TRY (hipFuncSetAttribute (fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)I.lds_bytes));
-    }
+    for (int co = 0; co < 2; co++)
+      HIP_TRY (hipFuncSetAttribute (dense_kernel_ptr (entry_bytes, p->streams, co != 0),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)I.lds_bytes));
   }
   *out = p;
   return ACM_GPU_OK;
@@ -704,6 +977,10 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
   }
   if (plan->blob)
     (void)hipFree (plan->blob);
+  if (plan->d_items)
+    (void)hipFree (plan->d_items);
+  if (plan->d_fill)
+    (void)hipFree (plan->d_fill);
   delete plan;
 }
 
@@ -770,21 +1047,18 @@ timing_begin (ACMPlan *p, hipStream_t st, hipEvent_t *stop) {
 
 template <bool COUNT_ONLY>
 int
-launch_csr (ACMPlan *p, const ScanArgs &base, uint64_t begin, uint64_t end, hipStream_t st) {
-  if (end <= begin)
+launch_csr (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
+  if (a.range_end <= a.range_begin)
     return ACM_GPU_OK;
-  ScanArgs a = base;
-  a.range_begin = begin;
-  a.range_end = end;
-  const uint64_t len = end - begin;
+  const uint64_t len = a.range_end - a.range_begin;
   /* chunk length: enough chunks to fill the chip, long enough to amortise the warm-up */
-  uint64_t target_lanes = (uint64_t)p->cu_count * 16 * WAVE;
+  const uint64_t target_lanes = (uint64_t)p->cu_count * 16 * WAVE;
   uint64_t chunk = (len + target_lanes - 1) / target_lanes;
   const uint64_t minchunk = 64 > 8ull * p->finfo.lmax ? 64 : 8ull * p->finfo.lmax;
   if (chunk < minchunk)
     chunk = minchunk;
-  if (chunk > 4096)
-    chunk = 4096;
+  if (chunk > 4096 && chunk > minchunk)
+    chunk = 4096 > minchunk ? 4096 : minchunk;
   const uint64_t nchunks = (len + chunk - 1) / chunk;
   uint64_t blocks = (nchunks + WAVE - 1) / WAVE;
   const uint64_t maxblocks = (uint64_t)p->cu_count * 32;
@@ -792,10 +1066,66 @@ launch_csr (ACMPlan *p, const ScanArgs &base, uint64_t begin, uint64_t end, hipS
     blocks = maxblocks;
   dim3 g ((uint32_t)blocks), b (WAVE);
   switch (p->finfo.sym_bytes) {
-  case 1: hipLaunchKernelGGL ((scan_csr_kernel<uint8_t, COUNT_ONLY>), g, b, 0, st, p->T, a, (uint32_t)chunk); break;
-  case 2: hipLaunchKernelGGL ((scan_csr_kernel<uint16_t, COUNT_ONLY>), g, b, 0, st, p->T, a, (uint32_t)chunk); break;
-  default: hipLaunchKernelGGL ((scan_csr_kernel<uint32_t, COUNT_ONLY>), g, b, 0, st, p->T, a, (uint32_t)chunk); break;
+  case 1: hipLaunchKernelGGL ((scan_csr_kernel<uint8_t, COUNT_ONLY>), g, b, 0, st, p->csr, E, a, (uint32_t)chunk); break;
+  case 2: hipLaunchKernelGGL ((scan_csr_kernel<uint16_t, COUNT_ONLY>), g, b, 0, st, p->csr, E, a, (uint32_t)chunk); break;
+  default: hipLaunchKernelGGL ((scan_csr_kernel<uint32_t, COUNT_ONLY>), g, b, 0, st, p->csr, E, a, (uint32_t)chunk); break;
   }
+  HIP_TRY (hipGetLastError ());
+  return ACM_GPU_OK;
+}
+
+/* (re)allocate the item buffer for segments of up to n symbols: room for one item per 256
+ * symbols, at least 256 per wave; denser matches are expanded in the kernel itself */
+int
+ensure_item_buffer (ACMPlan *p, uint64_t n) {
+  const uint32_t regions = p->info.grid_blocks * (DENSE_THREADS / WAVE);
+  uint64_t per = (n / 256 + regions - 1) / regions;
+  per = (per + 63) / 64 * 64;
+  if (per < 256)
+    per = 256;
+  if (per > (1u << 20))
+    per = 1u << 20;
+  if (p->d_items && p->regions == regions && p->region_items >= per)
+    return ACM_GPU_OK;
+  if (p->d_items)
+    HIP_TRY (hipFree (p->d_items));
+  if (p->d_fill)
+    HIP_TRY (hipFree (p->d_fill));
+  p->d_items = nullptr;
+  p->d_fill = nullptr;
+  if (hipMalloc (&p->d_items, (size_t)regions * per * 8) != hipSuccess)
+    return ACM_GPU_E_NOMEM;
+  if (hipMalloc (reinterpret_cast<void **> (&p->d_fill), (size_t)regions * 4) != hipSuccess)
+    return ACM_GPU_E_NOMEM;
+  p->regions = regions;
+  p->region_items = (uint32_t)per;
+  return ACM_GPU_OK;
+}
+
+template <bool COUNT_ONLY>
+int
+launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop) {
+  const uint32_t TILE = WAVE * p->streams * DENSE_C;
+  a.range_begin = 0;
+  a.range_end = (uint32_t)(((uint64_t)a.n + TILE - 1) / TILE);
+  uint32_t grid = p->info.grid_blocks;
+  const uint32_t wpb = DENSE_THREADS / WAVE;
+  const uint32_t blocks_needed = (a.range_end + wpb - 1) / wpb;
+  if (blocks_needed < grid)
+    grid = blocks_needed;
+  HIP_TRY (hipMemsetAsync (p->d_fill, 0, (size_t)p->regions * 4, st));
+  void *args[] = { &p->K, const_cast<EmitCtx *> (&E), &a, &p->d_dense, &p->d_lds_image, &p->lds_image_bytes, &a.text,
+                   &p->d_items, &p->region_items, &p->d_fill };
+  HIP_TRY (hipLaunchKernel (dense_kernel_ptr (p->entry_bytes, p->streams, COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), args,
+                            p->info.lds_bytes, st));
+  if (stop)
+    HIP_TRY (hipEventRecord (stop, st));
+  const dim3 eg (grid);
+  const uint2 *items = static_cast<const uint2 *> (p->d_items);
+  if (p->entry_bytes == 2)
+    hipLaunchKernelGGL ((expand_items_kernel<true, COUNT_ONLY>), eg, dim3 (EXPAND_THREADS), 0, st, E, items, p->region_items, p->d_fill);
+  else
+    hipLaunchKernelGGL ((expand_items_kernel<false, COUNT_ONLY>), eg, dim3 (EXPAND_THREADS), 0, st, E, items, p->region_items, p->d_fill);
   HIP_TRY (hipGetLastError ());
   return ACM_GPU_OK;
 }
@@ -808,50 +1138,60 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   HIP_TRY (hipMemsetAsync (d_count, 0, sizeof (uint64_t), st));
   if (n == 0 || p->finfo.n_edges == 0)
     return ACM_GPU_OK;
-  ScanArgs a{};
-  a.text = static_cast<const unsigned char *> (d_text);
-  a.n = n;
-  a.emit_from = emit_from;
-  a.pos_base = pos_base;
-  a.records = d_records;
-  a.capacity = COUNT_ONLY ? 0 : capacity;
-  a.count = reinterpret_cast<unsigned long long *> (d_count);
+  const uint32_t sb = p->finfo.sym_bytes;
+  const bool use_dense = p->info.kernel == 1 && (reinterpret_cast<uintptr_t> (d_text) & 15) == 0;
+  EmitCtx E{};
+  E.nb_outputs = p->csr.nb_outputs;
+  E.term_kw = p->c_term_kw;
+  E.out_link = p->c_out_link;
+  E.depth = p->c_depth;
+  E.records = d_records;
+  E.count = reinterpret_cast<unsigned long long *> (d_count);
+  E.capacity = COUNT_ONLY ? 0 : capacity;
+  E.wrows = p->d_wrows;
+  E.hotfail = p->d_hotfail;
+  E.W = p->K.W;
+  E.lo = p->K.lo;
+  E.span = p->K.span;
 
-  const uint64_t TILE = (uint64_t)WAVE * DENSE_S * DENSE_C;
-  if (p->info.kernel == 1 && (reinterpret_cast<uintptr_t> (d_text) & 15) == 0) {
-    /* one launch covers the whole buffer, ragged last tile included */
-    ScanArgs f = a;
-    f.range_begin = 0;
-    f.range_end = (n + TILE - 1) / TILE;
+  if (use_dense) {
+    int rc = ensure_item_buffer (p, n < SEGMENT ? n : SEGMENT);
+    if (rc)
+      return rc;
+  }
+  /* segments of at most SEGMENT symbols; each restarts from the root `halo` symbols early
+   * (a multiple of 16 bytes so that the dense kernel keeps its alignment) */
+  const uint64_t halo = p->finfo.lmax > 1 ? (((uint64_t)p->finfo.lmax - 1 + 15) / 16) * 16 : 0;
+  for (uint64_t seg = 0; seg < n; seg += SEGMENT) {
+    const uint64_t seg_end = seg + SEGMENT < n ? seg + SEGMENT : n;
+    if (seg_end <= emit_from)
+      continue; /* nothing to report from this segment */
+    const uint64_t read_begin = seg > halo ? seg - halo : 0;
+    Launch a{};
+    a.text = static_cast<const unsigned char *> (d_text) + read_begin * sb;
+    a.n = (uint32_t)(seg_end - read_begin);
+    const uint64_t ef = emit_from > seg ? emit_from : seg;
+    a.emit_from = (uint32_t)(ef - read_begin);
+    E.pos_base = pos_base + read_begin;
+    E.text = a.text;
+    E.n = a.n;
+    E.emit_from = a.emit_from;
     hipEvent_t stop;
     int rc = timing_begin (p, st, &stop);
     if (rc)
       return rc;
-    uint32_t grid = p->info.grid_blocks;
-    const uint64_t waves_needed = f.range_end;
-    const uint64_t blocks_needed = (waves_needed + DENSE_THREADS / WAVE - 1) / (DENSE_THREADS / WAVE);
-    if (blocks_needed < grid)
-      grid = (uint32_t)blocks_needed;
-    if (p->T.entry_bytes == 2)
-      hipLaunchKernelGGL (dense_kernel16 (COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), p->info.lds_bytes, st, p->T, f,
-                          static_cast<const uint16_t *> (p->T.dense), f.text, p->queue_off);
-    else
-      hipLaunchKernelGGL (dense_kernel32 (COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), p->info.lds_bytes, st, p->T, f,
-                          static_cast<const uint32_t *> (p->T.dense), f.text, p->queue_off);
-    HIP_TRY (hipGetLastError ());
-    if (stop)
-      HIP_TRY (hipEventRecord (stop, st));
-    return ACM_GPU_OK;
+    if (use_dense)
+      rc = launch_dense<COUNT_ONLY> (p, E, a, st, stop);
+    else {
+      a.range_begin = 0;
+      a.range_end = a.n;
+      rc = launch_csr<COUNT_ONLY> (p, E, a, st);
+      if (!rc && stop)
+        HIP_TRY (hipEventRecord (stop, st));
+    }
+    if (rc)
+      return rc;
   }
-  hipEvent_t stop;
-  int rc = timing_begin (p, st, &stop);
-  if (rc)
-    return rc;
-  rc = launch_csr<COUNT_ONLY> (p, a, 0, n, st);
-  if (rc)
-    return rc;
-  if (stop)
-    HIP_TRY (hipEventRecord (stop, st));
   return ACM_GPU_OK;
 }
 
@@ -916,8 +1256,8 @@ acm_gpu_sort_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, vo
   uint32_t len_bits = 1;
   while ((1u << len_bits) <= plan->finfo.lmax)
     len_bits++;
-  /* keys are relative to position 0 of the record space; 64 - len_bits bits remain for positions */
-  hipLaunchKernelGGL (make_keys_kernel, dim3 ((uint32_t)((n + 255) / 256)), dim3 (256), 0, st, d_records, n, 0ull, len_bits, k0);
+  /* key = end_pos in the high bits, (max - length) below: 64 - len_bits bits remain for positions */
+  hipLaunchKernelGGL (make_keys_kernel, dim3 ((uint32_t)((n + 255) / 256)), dim3 (256), 0, st, d_records, n, len_bits, k0);
   HIP_TRY (hipGetLastError ());
   hipcub::DoubleBuffer<uint64_t> keys (k0, k1);
   hipcub::DoubleBuffer<Rec16> vals (reinterpret_cast<Rec16 *> (d_records), v1);
@@ -1012,6 +1352,14 @@ acm_scan (ACMachine *machine, const void *text, uint64_t n_symbols, ACMRecord *r
   return acm_gpu_scan_host (plan, text, n_symbols, 0, 0, records, capacity, n_found);
 }
 
+#ifdef ACM_DIAG
+extern "C" int
+acm_gpu_diag_read (unsigned long long *out, unsigned waves) {
+  HIP_TRY (hipMemcpyFromSymbol (out, HIP_SYMBOL (g_acm_diag), sizeof (unsigned long long) * 8 * (waves < 8192 ? waves : 8192)));
+  return ACM_GPU_OK;
+}
+#endif
+
 /* ------------------------------------------------------------------ synthetic workload */
 extern "C" int
 acm_gpu_synth_text (int device, void *d_text, uint64_t n, uint64_t global_begin, uint32_t sym_bytes, uint32_t vocab,
@@ -1024,10 +1372,10 @@ acm_gpu_synth_text (int device, void *d_text, uint64_t n, uint64_t global_begin,
     return ACM_GPU_OK;
   dim3 g (4096), b (256);
   if (sym_bytes == 1)
-    hipLaunchKernelGGL (synth_text_kernel<uint8_t>, g, b, 0, st, static_cast<uint8_t *> (d_text), n, global_begin, 0ull, vocab,
+    hipLaunchKernelGGL (synth_text_kernel<uint8_t>, g, b, 0, st, static_cast<uint8_t *> (d_text), n, global_begin, vocab,
                         static_cast<const uint8_t *> (d_kw_data), d_kw_off, n_kw);
   else
-    hipLaunchKernelGGL (synth_text_kernel<uint32_t>, g, b, 0, st, static_cast<uint32_t *> (d_text), n, global_begin, 0ull, vocab,
+    hipLaunchKernelGGL (synth_text_kernel<uint32_t>, g, b, 0, st, static_cast<uint32_t *> (d_text), n, global_begin, vocab,
                         static_cast<const uint32_t *> (d_kw_data), d_kw_off, n_kw);
   HIP_TRY (hipGetLastError ());
   return ACM_GPU_OK;

@@ -156,9 +156,9 @@ def main():
                             "1 keyword planted per 4096 B" % (args.keywords, args.mib),
                 "states": int(m.flatten().info.n_states), "lmax": lmax, "matches_per_gpu": n_matches,
                 "matches_total": total_matches, "parallelism": "text sharded x%d, 16 B halo, tables replicated" % world,
-                "kernel": "scan_dense_kernel<u%d,C=%d,S=%d> %d x %d threads, %d LDS rows of %d, %d B LDS" % (
+                "kernel": "scan_dense_kernel<u%d,C=%d,S=%d> %d x %d threads; LDS: %d rows + %d hotfail entries of %d states, %d B" % (
                     8 * info["entry_bytes"], info["chunk_bytes"], info["streams"], info["grid_blocks"],
-                    info["block_threads"], info["lds_rows"], info["dense_rows"], info["lds_bytes"]),
+                    info["block_threads"], info["lds_rows"], info["lds_hotfail"], info["dense_rows"], info["lds_bytes"]),
                 "dictionary_build_s": round(build_s, 3),
             },
             "roofline": {

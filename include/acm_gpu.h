@@ -97,11 +97,12 @@ typedef struct ACMPlan ACMPlan;
 
 typedef struct {
   int device;
-  uint32_t kernel;       /* 1 = dense-row byte kernel (LDS-resident hot rows), 2 = CSR kernel (any symbol size) */
+  uint32_t kernel;       /* 1 = dense-row byte kernel (automaton in LDS), 2 = CSR kernel (any symbol size) */
   uint32_t entry_bytes;  /* dense entries: 2 or 4 */
   uint32_t width;        /* dense row width */
   uint32_t dense_rows;   /* rows resident in HBM */
-  uint32_t lds_rows;     /* of which staged in LDS by every workgroup */
+  uint32_t lds_rows;     /* states whose failure-resolved row is staged in LDS by every workgroup */
+  uint32_t lds_hotfail;  /* further states for which LDS holds the nearest failure-chain state that has a row (2 B each) */
   uint32_t lds_bytes;    /* dynamic LDS per workgroup */
   uint32_t block_threads;
   uint32_t grid_blocks;
@@ -119,7 +120,7 @@ void acm_gpu_plan_info (const ACMPlan *plan, ACMPlanInfo *info);
 
 /* Scan d_text[0 .. n_symbols) from the root state.  Matches whose end index is < emit_from are
  * not reported (warm-up region of a shard: pass the lmax - 1 symbols preceding the shard and
- * emit_from = their number).  Reported end_pos = pos_base + index - emit_from... see below.
+ * emit_from = their number).
  *
  *   end_pos of a match ending at buffer index i  =  pos_base + i
  *
