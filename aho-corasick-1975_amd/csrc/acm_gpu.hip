@@ -96,14 +96,14 @@ struct Launch {
 struct DenseK {
   uint32_t W, rowbytes, lo, span;
   uint32_t HD; /* states [0, HD): failure-resolved row in LDS */
-  uint32_t aux_off, queue_off, wub;
+  uint32_t aux_off, queue_off, wub, lmax;
 };
 
 /* queue item, second word, when the dense kernel runs in continuation mode (16-bit states) */
 constexpr uint32_t IT_STATE = 0x7FFFu;
 constexpr uint32_t IT_CONT = 1u << 15;  /* walk on from this (rowless) state: see walk_continuation */
-constexpr uint32_t IT_SKIP_SHIFT = 16;  /* 12 bits: positions after pos that belong to the previous chunk */
-constexpr uint32_t IT_WARM = 1u << 28;  /* queued during a chunk's warm-up */
+constexpr uint32_t IT_K_SHIFT = 16;     /* 12 bits: run-over step k (symbols past the end of the lane's chunk) */
+constexpr uint32_t IT_RUN = 1u << 28;   /* queued during a chunk's run-over */
 constexpr uint32_t IT_OUT = 1u << 29;   /* report the outputs of the state itself at pos */
 
 /* ------------------------------------------------------------------ wave helpers */
@@ -157,41 +157,45 @@ struct ContResult {
   uint32_t ev_pos, ev_state, ev_bound; /* the first of them */
 };
 
-/* Continuation item (dense kernel with 16-bit states): at `pos` the lane stepped into a state s
- * that has no row in LDS and carried on from hotfail(s), the longest suffix state that has one.
- * From there it still finds every match that starts within the last depth(hotfail(s)) symbols or
- * later; the matches it can no longer see are the ones that started earlier and end after pos.
- * They are recovered here: walk on from s itself through the HBM rows; after k more symbols every
- * output longer than k + depth(hotfail(s)) is such a match; once the state's depth is <= that
- * bound nothing more can be missing.  The walk stops at the end of the lane's chunk (later ends
- * belong to the next chunk's owner, which finds them from its own warm-up).
+/* Ownership in the continuation-mode dense kernel: a match belongs to the chunk in which it
+ * STARTS.  A lane starts from the root at the first byte of its chunk [cs, ce), walks the chunk
+ * and then runs over into the following bytes until its state is no deeper than the number of
+ * bytes past ce (no match that started before ce can still be open); during that run-over only
+ * outputs longer than the bytes past ce are its own.
+ *
+ * Continuation item: at `pos` the lane stepped into a state s that has no row in LDS and carried
+ * on from hotfail(s), the longest suffix state that has one (depth dh).  From there it still finds
+ * every match that starts within the last dh symbols or later; the ones it can no longer see
+ * started earlier and end after pos.  They are recovered here by walking on from s itself
+ * through the HBM rows: j symbols later every output longer than j + dh -- and, past ce, longer
+ * than the bytes past ce -- is such a match, and once the state is no deeper than that bound
+ * nothing more can be missing.
  * One dependent load per symbol: the row entry carries the next state, its output flag and its
  * depth; the text byte of the following step is fetched alongside. */
+__device__ __forceinline__ uint32_t
+item_chunk_end (uint2 it) {
+  return (it.y & IT_RUN) ? it.x + 1 - ((it.y >> IT_K_SHIFT) & 0xFFFu) : (it.x | (DENSE_C - 1)) + 1;
+}
+
 template <bool WRITE>
 __device__ __forceinline__ ContResult
 walk_continuation (const EmitCtx &E, uint2 it, uint64_t o) {
   ContResult r = { 0, 0, 0, 0, 0 };
   const uint32_t pos = it.x, st = it.y & IT_STATE;
   const uint32_t dh = E.depth[E.hotfail[st]];
-  uint32_t own_begin = 0, chunk_end = (pos | (DENSE_C - 1)) + 1;
-  if (it.y & IT_WARM) {
-    own_begin = pos + ((it.y >> IT_SKIP_SHIFT) & 0xFFFu) + 1;
-    chunk_end = own_begin + DENSE_C;
-  }
-  if (own_begin < E.emit_from)
-    own_begin = E.emit_from;
-  const uint32_t lim = chunk_end < E.n ? chunk_end : E.n;
+  const uint32_t ce = item_chunk_end (it);
   uint32_t s2 = st;
-  uint32_t byte = pos + 1 < lim ? E.text[pos + 1] : 0;
-  for (uint32_t k = 1; pos + k < lim; k++) {
-    const uint32_t p = pos + k;
+  uint32_t byte = pos + 1 < E.n ? E.text[pos + 1] : 0;
+  for (uint32_t j = 1; pos + j < E.n; j++) {
+    const uint32_t p = pos + j;
     const uint32_t ent = E.wrows[s2 * E.W + min (byte - E.lo, E.span)];
-    byte = p + 1 < lim ? E.text[p + 1] : 0;
+    byte = p + 1 < E.n ? E.text[p + 1] : 0;
     s2 = ent & IT_STATE;
-    const uint32_t bound = k + dh;
+    const uint32_t past = p + 1 > ce ? p + 1 - ce : 0;
+    const uint32_t bound = j + dh > past ? j + dh : past;
     if ((ent >> 16) <= bound)
       break;
-    if ((ent & 0x8000u) && p >= own_begin) {
+    if ((ent & 0x8000u) && p >= E.emit_from) {
       const uint32_t c = put_outputs<WRITE> (E, s2, p, bound, o + r.cnt);
       if (c) {
         if (!r.events) {
@@ -213,7 +217,13 @@ __device__ __forceinline__ uint32_t
 item_count (const EmitCtx &E, bool valid, uint2 it, uint32_t &own_cnt, ContResult &r) {
   const uint32_t st = CONT ? (it.y & IT_STATE) : it.y;
   const bool own = valid && (!CONT || (it.y & IT_OUT));
-  own_cnt = own ? E.nb_outputs[st] : 0;
+  own_cnt = 0;
+  if (own) {
+    if (CONT && (it.y & IT_RUN)) /* run-over: only outputs longer than the bytes past the chunk */
+      own_cnt = put_outputs<false> (E, st, it.x, (it.y >> IT_K_SHIFT) & 0xFFFu, 0);
+    else
+      own_cnt = E.nb_outputs[st];
+  }
   r = ContResult{ 0, 0, 0, 0, 0 };
   if (CONT && valid && (it.y & IT_CONT))
     r = walk_continuation<false> (E, it, 0);
@@ -226,7 +236,7 @@ __device__ __forceinline__ void
 item_write (const EmitCtx &E, uint2 it, uint32_t own_cnt, const ContResult &r, uint64_t o) {
   const uint32_t st = CONT ? (it.y & IT_STATE) : it.y;
   if (own_cnt)
-    (void)put_outputs<true> (E, st, it.x, 0, o);
+    (void)put_outputs<true> (E, st, it.x, (CONT && (it.y & IT_RUN)) ? ((it.y >> IT_K_SHIFT) & 0xFFFu) : 0u, o);
   if (r.events == 1)
     (void)put_outputs<true> (E, r.ev_state, r.ev_pos, r.ev_bound, o + own_cnt);
   else if (r.events > 1)
@@ -389,11 +399,13 @@ lds_row_entry (uint32_t state, uint32_t rowbytes, uint32_t cls) {
   return *reinterpret_cast<const __attribute__ ((address_space (3))) ENTRY *> (addr);
 }
 
-/* where a step is: pos0 = position of stream 0's byte; in a warm-up block, `back` = distance from
- * the block start to the chunk start and `skip` = positions between this byte and the chunk */
+/* where a step is: pos0 = position of stream 0's byte; phase MAIN (inside the chunk), WARM
+ * (sticky mode: before the chunk, nothing is reported) or RUN (continuation mode: k bytes past
+ * the chunk, live_from = first state id of depth k + 1) */
+enum { PH_MAIN = 0, PH_WARM = 1, PH_RUN = 2 };
 struct StepAt {
-  uint32_t pos0, back, skip;
-  bool emit;
+  uint32_t pos0, k, live_from;
+  int phase;
 };
 
 /* Slow side of one step: the whole wave comes here when some lane looked up an entry >= HD (next
@@ -413,18 +425,20 @@ dense_step_slow (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t
     if (!CONT && w.s[q] >= K.HD) /* sticky mode: the LDS lookup was meaningless, redo it from HBM */
       e[q] = gdense[w.s[q] * K.W + cls[q]];
     uint32_t ns = e[q] & IDMASK;
-    const bool out = at.emit && (e[q] & FLAG) && pos >= emit_from && pos < emit_end;
+    const bool window = pos >= emit_from && pos < emit_end;
     if (CONT) {
-      /* a warm-up block that would start before the segment is walked on filler and discarded */
-      const bool real = at.emit || pos + at.skip + 1 >= at.back;
-      const bool deep = ns >= K.HD && real && pos < emit_end;
+      /* run-over: a lane whose state is no deeper than k has nothing of its own left */
+      const bool live = at.phase != PH_RUN || ns >= at.live_from;
+      const bool out = live && (e[q] & FLAG) && window;
+      const bool deep = live && ns >= K.HD && pos < emit_end;
       uint32_t word = ns | (deep ? IT_CONT : 0u) | (out ? IT_OUT : 0u);
-      if (!at.emit)
-        word |= IT_WARM | (at.skip << IT_SKIP_SHIFT);
+      if (at.phase == PH_RUN)
+        word |= IT_RUN | (at.k << IT_K_SHIFT);
       queue_push<CONT, COUNT_ONLY> (E, queue, w.qn, out | deep, pos, word, lane, &w.spill);
       if (ns >= K.HD)
         ns = *reinterpret_cast<const __attribute__ ((address_space (3))) uint16_t *> (K.aux_off + (ns - K.HD) * 2u);
     } else {
+      const bool out = at.phase == PH_MAIN && (e[q] & FLAG) && window;
       queue_push<CONT, COUNT_ONLY> (E, queue, w.qn, out, pos, ns, lane, &w.spill);
       rowless |= ns >= K.HD;
     }
@@ -471,7 +485,7 @@ dense_block (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emi
   {                                                                                                \
     uint32_t b_[S];                                                                                \
     _Pragma ("unroll") for (int q = 0; q < S; q++) b_[q] = (blk[q].COMP >> (SH)) & 0xffu;          \
-    const StepAt at_ = { at.pos0 + (J), at.back, at.skip - (J), at.emit };                         \
+    const StepAt at_ = { at.pos0 + (J), 0, 0, at.phase };                                          \
     dense_step<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, b_, at_, lane); \
   }
 #define ACM_WORD(COMP, J)                                                                          \
@@ -486,7 +500,7 @@ template <typename ENTRY, int S, bool COUNT_ONLY, int K0, int KN> struct BlockLo
   static __device__ __forceinline__ void
   run (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emit_end, const ENTRY *__restrict__ gdense,
        uint2 *queue, Walk<S> &w, const uint4 (&d)[KN][S], uint32_t pos0, uint32_t lane) {
-    const StepAt at = { pos0 + 16 * K0, 0, 0, true };
+    const StepAt at = { pos0 + 16 * K0, 0, 0, PH_MAIN };
     dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[K0], at, lane);
     BlockLoop<ENTRY, S, COUNT_ONLY, K0 + 1, KN>::run (K, E, emit_from, emit_end, gdense, queue, w, d, pos0, lane);
   }
@@ -506,7 +520,7 @@ template <typename ENTRY, int C, int S, bool COUNT_ONLY>
 __global__ __launch_bounds__ (DENSE_THREADS) void
 scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gdense, const uint4 *__restrict__ lds_image,
                    uint32_t lds_image_bytes, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
-                   uint32_t *fill) {
+                   uint32_t *fill, const uint32_t *__restrict__ dstart) {
   extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
   constexpr uint32_t TILE = WAVE * S * C;
   constexpr int NB = C / 16;
@@ -553,26 +567,59 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
     }
     w.sticky = 0;
     DIAG (asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); d_text += __builtin_readcyclecounter () - d_tl; d_tiles++;)
-    /* warm-up: wub 16-byte blocks before each chunk, walked from the root without reporting
-     * (matches ending there belong to the previous chunk's owner).  A chunk closer than that to
-     * the start of the segment starts from the root at its first in-range block instead. */
-    for (uint32_t b = K.wub; b >= 1; b--) {
-      uint4 pre[S];
-      const uint32_t back = 16u * b;
+    if (!CONT) {
+      /* sticky mode, ownership by END position.  Warm-up: wub 16-byte blocks before each chunk,
+       * walked from the root without reporting (matches ending there belong to the previous
+       * chunk's owner).  A chunk closer than that to the start of the segment starts from the
+       * root at its first in-range block instead. */
+      for (uint32_t b = K.wub; b >= 1; b--) {
+        uint4 pre[S];
+        const uint32_t back = 16u * b;
 #pragma unroll
-      for (int q = 0; q < S; q++) {
-        const uint32_t cs = pos0 + q * (WAVE * C);
-        const uint32_t off = cs >= back ? cs - back : 0;
-        pre[q] = *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
+        for (int q = 0; q < S; q++) {
+          const uint32_t cs = pos0 + q * (WAVE * C);
+          const uint32_t off = cs >= back ? cs - back : 0;
+          pre[q] = *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
+        }
+        const StepAt at = { pos0 - back, 0, 0, PH_WARM };
+        dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, pre, at, lane);
+#pragma unroll
+        for (int q = 0; q < S; q++)
+          if (pos0 + q * (WAVE * C) < back)
+            w.s[q] = 0;
       }
-      const StepAt at = { pos0 - back, back, back - 1, false };
-      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, pre, at, lane);
-#pragma unroll
-      for (int q = 0; q < S; q++)
-        if (pos0 + q * (WAVE * C) < back)
-          w.s[q] = 0;
     }
     BlockLoop<ENTRY, S, COUNT_ONLY, 0, NB>::run (K, E, emit_from, emit_end, gdense, queue, w, d, pos0, lane);
+    if (CONT) {
+      /* continuation mode, ownership by START position: run over into the following bytes until
+       * no lane's state is deeper than the number of bytes past its chunk (at most lmax - 1) */
+      bool done = false;
+      for (uint32_t b = 0; b < K.wub && !done; b++) {
+        uint4 post[S];
+#pragma unroll
+        for (int q = 0; q < S; q++) {
+          const uint32_t off = pos0 + q * (WAVE * C) + C + 16 * b;
+          post[q] = *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
+        }
+#define ACM_RUN_BYTE(COMP, SH, J)                                                                  \
+  if (!done) {                                                                                     \
+    const uint32_t k_ = 16 * b + (J) + 1;                                                          \
+    const uint32_t live_from_ = dstart[k_ + 1 <= K.lmax ? k_ + 1 : K.lmax + 1];                    \
+    uint32_t b_[S];                                                                                \
+    _Pragma ("unroll") for (int q = 0; q < S; q++) b_[q] = (post[q].COMP >> (SH)) & 0xffu;         \
+    const StepAt at_ = { pos0 + C + 16 * b + (J), k_, live_from_, PH_RUN };                        \
+    dense_step<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, b_, at_, lane); \
+    bool live_ = false;                                                                            \
+    _Pragma ("unroll") for (int q = 0; q < S; q++) live_ |= w.s[q] >= live_from_;                  \
+    done = k_ + 1 >= K.lmax || __ballot (live_) == 0;                                              \
+  }
+#define ACM_RUN_WORD(COMP, J)                                                                      \
+  ACM_RUN_BYTE (COMP, 0, (J) + 0) ACM_RUN_BYTE (COMP, 8, (J) + 1) ACM_RUN_BYTE (COMP, 16, (J) + 2) ACM_RUN_BYTE (COMP, 24, (J) + 3)
+        ACM_RUN_WORD (x, 0) ACM_RUN_WORD (y, 4) ACM_RUN_WORD (z, 8) ACM_RUN_WORD (w, 12)
+#undef ACM_RUN_WORD
+#undef ACM_RUN_BYTE
+      }
+    }
   }
   if (w.qn)
     queue_drain<CONT, COUNT_ONLY> (E, queue, w.qn, &w.spill, lane);
@@ -712,6 +759,7 @@ struct ACMPlan {
   const void *d_dense = nullptr;     /* failure-resolved rows of every state */
   const void *d_lds_image = nullptr; /* what every workgroup copies into LDS */
   const uint32_t *d_wrows = nullptr;
+  const uint32_t *d_dstart = nullptr;
   const uint16_t *d_hotfail = nullptr;
   uint32_t lds_image_bytes = 0;
   uint32_t entry_bytes = 0, streams = 2;
@@ -862,6 +910,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const size_t o_dense = blob_reserve (cur, dense_bytes + 16);
   const size_t o_hotfail = blob_reserve (cur, cont ? (size_t)n * 2 : 0);
   const size_t o_wrows = blob_reserve (cur, cont ? (size_t)n * fi.width * 4 : 0);
+  const size_t o_dstart = blob_reserve (cur, ((size_t)fi.lmax + 2) * 4);
   const uint32_t rows_lds = dense ? ((HD * rowbytes + 15) & ~15u) : 0;
   const uint32_t image_bytes = dense ? ((rows_lds + (cont ? (n - HD) * 2 : 0) + 15) & ~15u) : 0;
   const size_t o_image = blob_reserve (cur, image_bytes + 16);
@@ -876,6 +925,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   memcpy (&host[o_cterm], fv.term_kw, (size_t)n * 4);
   memcpy (&host[o_clink], fv.out_link, (size_t)n * 4);
   memcpy (&host[o_cdepth], fv.depth, (size_t)n * 4);
+  memcpy (&host[o_dstart], fv.depth_start, ((size_t)fi.lmax + 2) * 4);
   if (dense) {
     int rc = acm_flat_dense_rows (flat, n, entry_bytes, &host[o_dense]);
     if (rc) {
@@ -929,7 +979,9 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     K.aux_off = rows_lds;
     K.queue_off = image_bytes;
     K.wub = fi.lmax > 1 ? (fi.lmax - 1 + 15) / 16 : 0;
+    K.lmax = fi.lmax;
   }
+  p->d_dstart = u32p (o_dstart);
 
   ACMPlanInfo &I = p->info;
   I.device = device;
@@ -1115,7 +1167,7 @@ launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
     grid = blocks_needed;
   HIP_TRY (hipMemsetAsync (p->d_fill, 0, (size_t)p->regions * 4, st));
   void *args[] = { &p->K, const_cast<EmitCtx *> (&E), &a, &p->d_dense, &p->d_lds_image, &p->lds_image_bytes, &a.text,
-                   &p->d_items, &p->region_items, &p->d_fill };
+                   &p->d_items, &p->region_items, &p->d_fill, &p->d_dstart };
   HIP_TRY (hipLaunchKernel (dense_kernel_ptr (p->entry_bytes, p->streams, COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), args,
                             p->info.lds_bytes, st));
   if (stop)
