@@ -551,20 +551,35 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
   w.spill.fill = 0;
   DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_text = 0, d_tiles = 0;)
 
-  for (uint32_t tile = A.range_begin + wave; tile < A.range_end; tile += nwaves) {
-    const uint32_t tbase = tile * TILE;
-    DIAG (const unsigned long long d_tl = __builtin_readcyclecounter ();)
-    const uint32_t pos0 = tbase + lane * C; /* first byte of this lane's stream 0 */
-    uint4 d[NB][S];
+  static_assert (NB == 4, "the software pipeline below is written for 4 blocks per chunk");
+  /* text registers: d[k][q] = block k of stream q's chunk, post[q] = the 16 bytes after it.
+   * Software pipeline without extra registers: as soon as a block has been walked its registers
+   * receive the same block of the wave's NEXT tile, so every load has at least half a tile of
+   * walking (thousands of cycles) to land. */
+  uint4 d[NB][S], post[S];
+  auto load_block = [&] (uint32_t p0, int k, int q) -> uint4 {
+    const uint32_t off = p0 + q * (WAVE * C) + 16 * k;
+    return *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
+  };
+  {
+    const uint32_t p0 = (A.range_begin + wave) * TILE + lane * C;
 #pragma unroll
     for (int q = 0; q < S; q++) {
 #pragma unroll
-      for (int k = 0; k < NB; k++) {
-        const uint32_t off = pos0 + q * (WAVE * C) + 16 * k;
-        d[k][q] = *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
-      }
-      w.s[q] = 0;
+      for (int k = 0; k < NB; k++)
+        d[k][q] = load_block (p0, k, q);
+      post[q] = load_block (p0, NB, q);
     }
+  }
+
+  for (uint32_t tile = A.range_begin + wave; tile < A.range_end; tile += nwaves) {
+    const uint32_t tbase = tile * TILE;
+    const uint32_t pos0 = tbase + lane * C;        /* first byte of this lane's stream 0 */
+    const uint32_t npos0 = pos0 + nwaves * TILE;   /* the same lane's place in the wave's next tile */
+    DIAG (const unsigned long long d_tl = __builtin_readcyclecounter ();)
+#pragma unroll
+    for (int q = 0; q < S; q++)
+      w.s[q] = 0;
     w.sticky = 0;
     DIAG (asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); d_text += __builtin_readcyclecounter () - d_tl; d_tiles++;)
     if (!CONT) {
@@ -589,17 +604,33 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
             w.s[q] = 0;
       }
     }
-    BlockLoop<ENTRY, S, COUNT_ONLY, 0, NB>::run (K, E, emit_from, emit_end, gdense, queue, w, d, pos0, lane);
+    {
+      const StepAt a0 = { pos0, 0, 0, PH_MAIN }, a1 = { pos0 + 16, 0, 0, PH_MAIN };
+      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[0], a0, lane);
+      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[1], a1, lane);
+#pragma unroll
+      for (int q = 0; q < S; q++) {
+        d[0][q] = load_block (npos0, 0, q);
+        d[1][q] = load_block (npos0, 1, q);
+      }
+      const StepAt a2 = { pos0 + 32, 0, 0, PH_MAIN }, a3 = { pos0 + 48, 0, 0, PH_MAIN };
+      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[2], a2, lane);
+      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[3], a3, lane);
+#pragma unroll
+      for (int q = 0; q < S; q++) {
+        d[2][q] = load_block (npos0, 2, q);
+        d[3][q] = load_block (npos0, 3, q);
+      }
+    }
     if (CONT) {
       /* continuation mode, ownership by START position: run over into the following bytes until
        * no lane's state is deeper than the number of bytes past its chunk (at most lmax - 1) */
       bool done = false;
       for (uint32_t b = 0; b < K.wub && !done; b++) {
-        uint4 post[S];
+        if (b > 0) {
 #pragma unroll
-        for (int q = 0; q < S; q++) {
-          const uint32_t off = pos0 + q * (WAVE * C) + C + 16 * b;
-          post[q] = *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
+          for (int q = 0; q < S; q++)
+            post[q] = load_block (pos0, NB + b, q);
         }
 #define ACM_RUN_BYTE(COMP, SH, J)                                                                  \
   if (!done) {                                                                                     \
@@ -619,6 +650,9 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
 #undef ACM_RUN_WORD
 #undef ACM_RUN_BYTE
       }
+#pragma unroll
+      for (int q = 0; q < S; q++)
+        post[q] = load_block (npos0, NB, q);
     }
   }
   if (w.qn)
