@@ -71,16 +71,19 @@ struct CsrTables {
   uint32_t lmax;
 };
 
-/* what turns a queued (position, state) into records; states in the numbering of the kernel
- * that queued them.  The second half serves the continuations of the dense kernel. */
+/* what turns a queued (position, state) into records; states in breadth-first numbering.
+ * oinfo[s] = { nb_outputs(s), next, length, keyword_id } describes the FIRST output of s (the
+ * longest keyword ending there: s itself if terminal, else the nearest terminal state down its
+ * failure chain) and `next` = the terminal state holding the following one: one 16-byte load per
+ * record.  The second half serves the continuations of the dense kernel. */
 struct EmitCtx {
-  const uint32_t *nb_outputs, *term_kw, *out_link, *depth;
+  const uint4 *oinfo;
   ACMRecord *records;
-  unsigned long long *count;
+  unsigned long long *count; /* running total of records: slots are reserved by atomicAdd on it */
   uint64_t capacity, pos_base;
   const unsigned char *text;  /* segment */
   const uint32_t *wrows;      /* continuation rows of every state: next | out flag << 15 | depth(next) << 16 */
-  const uint16_t *hotfail;    /* per state: nearest state on its failure chain whose row is in LDS */
+  const uint16_t *cont_dh;    /* per state: depth of the nearest failure-chain state whose row is in LDS */
   uint32_t W, lo, span, n, emit_from;
 };
 
@@ -128,24 +131,23 @@ wave_incl_scan (uint32_t v) {
   return v;
 }
 
-/* outputs of state st longer than `bound`, in acm_get_match index order (the state itself if
- * terminal, then the chain of out_link: reference aho_corasick.c:459-466; lengths descend along
- * the chain): counted, and written from offset o when WRITE */
+/* outputs of state st longer than `bound`, in acm_get_match index order (longest first:
+ * reference aho_corasick.c:459-466): counted, and written from offset o when WRITE.  `oi` is
+ * oinfo[st], already loaded by the caller. */
 template <bool WRITE>
 __device__ __forceinline__ uint32_t
-put_outputs (const EmitCtx &E, uint32_t st, uint32_t pos, uint32_t bound, uint64_t o) {
+put_outputs (const EmitCtx &E, uint4 oi, uint32_t pos, uint32_t bound, uint64_t o) {
   uint32_t cnt = 0;
-  uint32_t t = E.term_kw[st] != NONE ? st : E.out_link[st];
-  while (t) {
-    const uint32_t len = E.depth[t];
-    if (len <= bound)
+  for (uint32_t left = oi.x; left; left--) {
+    if (oi.z <= bound)
       break;
     if (WRITE && o + cnt < E.capacity) {
       const uint64_t gp = E.pos_base + pos;
-      *reinterpret_cast<uint4 *> (&E.records[o + cnt]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), len, E.term_kw[t]);
+      *reinterpret_cast<uint4 *> (&E.records[o + cnt]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), oi.z, oi.w);
     }
     cnt++;
-    t = E.out_link[t];
+    if (left > 1)
+      oi = E.oinfo[oi.y];
   }
   return cnt;
 }
@@ -154,7 +156,8 @@ put_outputs (const EmitCtx &E, uint32_t st, uint32_t pos, uint32_t bound, uint64
 struct ContResult {
   uint32_t cnt;      /* records in all */
   uint32_t events;   /* positions with records */
-  uint32_t ev_pos, ev_state, ev_bound; /* the first of them */
+  uint32_t ev_pos, ev_bound; /* the first of them ... */
+  uint4 ev_oi;               /* ... and the oinfo of the state reached there */
 };
 
 /* Ownership in the continuation-mode dense kernel: a match belongs to the chunk in which it
@@ -180,9 +183,9 @@ item_chunk_end (uint2 it) {
 template <bool WRITE>
 __device__ __forceinline__ ContResult
 walk_continuation (const EmitCtx &E, uint2 it, uint64_t o) {
-  ContResult r = { 0, 0, 0, 0, 0 };
+  ContResult r = { 0, 0, 0, 0, make_uint4 (0, 0, 0, 0) };
   const uint32_t pos = it.x, st = it.y & IT_STATE;
-  const uint32_t dh = E.depth[E.hotfail[st]];
+  const uint32_t dh = E.cont_dh[st];
   const uint32_t ce = item_chunk_end (it);
   uint32_t s2 = st;
   uint32_t byte = pos + 1 < E.n ? E.text[pos + 1] : 0;
@@ -196,11 +199,12 @@ walk_continuation (const EmitCtx &E, uint2 it, uint64_t o) {
     if ((ent >> 16) <= bound)
       break;
     if ((ent & 0x8000u) && p >= E.emit_from) {
-      const uint32_t c = put_outputs<WRITE> (E, s2, p, bound, o + r.cnt);
+      const uint4 oi = E.oinfo[s2];
+      const uint32_t c = put_outputs<WRITE> (E, oi, p, bound, o + r.cnt);
       if (c) {
         if (!r.events) {
           r.ev_pos = p;
-          r.ev_state = s2;
+          r.ev_oi = oi;
           r.ev_bound = bound;
         }
         r.events++;
@@ -214,17 +218,19 @@ walk_continuation (const EmitCtx &E, uint2 it, uint64_t o) {
 /* number of records of one queue item (walks its continuation, remembering what it found) */
 template <bool CONT>
 __device__ __forceinline__ uint32_t
-item_count (const EmitCtx &E, bool valid, uint2 it, uint32_t &own_cnt, ContResult &r) {
+item_count (const EmitCtx &E, bool valid, uint2 it, uint32_t &own_cnt, uint4 &own_oi, ContResult &r) {
   const uint32_t st = CONT ? (it.y & IT_STATE) : it.y;
   const bool own = valid && (!CONT || (it.y & IT_OUT));
   own_cnt = 0;
+  own_oi = make_uint4 (0, 0, 0, 0);
   if (own) {
+    own_oi = E.oinfo[st];
     if (CONT && (it.y & IT_RUN)) /* run-over: only outputs longer than the bytes past the chunk */
-      own_cnt = put_outputs<false> (E, st, it.x, (it.y >> IT_K_SHIFT) & 0xFFFu, 0);
+      own_cnt = put_outputs<false> (E, own_oi, it.x, (it.y >> IT_K_SHIFT) & 0xFFFu, 0);
     else
-      own_cnt = E.nb_outputs[st];
+      own_cnt = own_oi.x;
   }
-  r = ContResult{ 0, 0, 0, 0, 0 };
+  r = ContResult{ 0, 0, 0, 0, make_uint4 (0, 0, 0, 0) };
   if (CONT && valid && (it.y & IT_CONT))
     r = walk_continuation<false> (E, it, 0);
   return own_cnt + r.cnt;
@@ -233,12 +239,11 @@ item_count (const EmitCtx &E, bool valid, uint2 it, uint32_t &own_cnt, ContResul
 /* writes them from offset o: the state's own outputs first, then the continuation's */
 template <bool CONT>
 __device__ __forceinline__ void
-item_write (const EmitCtx &E, uint2 it, uint32_t own_cnt, const ContResult &r, uint64_t o) {
-  const uint32_t st = CONT ? (it.y & IT_STATE) : it.y;
+item_write (const EmitCtx &E, uint2 it, uint32_t own_cnt, uint4 own_oi, const ContResult &r, uint64_t o) {
   if (own_cnt)
-    (void)put_outputs<true> (E, st, it.x, (CONT && (it.y & IT_RUN)) ? ((it.y >> IT_K_SHIFT) & 0xFFFu) : 0u, o);
+    (void)put_outputs<true> (E, own_oi, it.x, (CONT && (it.y & IT_RUN)) ? ((it.y >> IT_K_SHIFT) & 0xFFFu) : 0u, o);
   if (r.events == 1)
-    (void)put_outputs<true> (E, r.ev_state, r.ev_pos, r.ev_bound, o + own_cnt);
+    (void)put_outputs<true> (E, r.ev_oi, r.ev_pos, r.ev_bound, o + own_cnt);
   else if (r.events > 1)
     (void)walk_continuation<true> (E, it, o + own_cnt);
 }
@@ -254,8 +259,9 @@ flush_queue (EmitCtx E, const uint2 *queue, uint32_t n_items) {
     const bool valid = i < n_items;
     const uint2 it = valid ? queue[i] : make_uint2 (0, 0);
     uint32_t own_cnt;
+    uint4 own_oi;
     ContResult r;
-    const uint32_t cnt = item_count<CONT> (E, valid, it, own_cnt, r);
+    const uint32_t cnt = item_count<CONT> (E, valid, it, own_cnt, own_oi, r);
     const uint32_t incl = wave_incl_scan (cnt);
     const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
     unsigned long long gbase = 0;
@@ -263,7 +269,7 @@ flush_queue (EmitCtx E, const uint2 *queue, uint32_t n_items) {
       gbase = atomicAdd (E.count, (unsigned long long)total);
     gbase = ((unsigned long long)__shfl ((uint32_t)(gbase >> 32), 0, WAVE) << 32) | __shfl ((uint32_t)gbase, 0, WAVE);
     if (!COUNT_ONLY && cnt)
-      item_write<CONT> (E, it, own_cnt, r, gbase + (incl - cnt));
+      item_write<CONT> (E, it, own_cnt, own_oi, r, gbase + (incl - cnt));
   }
 }
 
@@ -305,51 +311,59 @@ queue_push (const EmitCtx &E, uint2 *queue, uint32_t &qn, bool hit, uint32_t pos
   }
 }
 
-/* Expands the items parked by one workgroup of the dense kernel (its 16 waves' regions): 1024
- * threads take 1024 items per round, a block-wide prefix sum of the per-item record counts gives
- * every item its slot, and ONE global atomic per round reserves the records (a single counter
- * sustains only ~90 atomics per microsecond, so they are kept to a few hundred per launch). */
-constexpr int EXPAND_THREADS = 1024;
-constexpr int EXPAND_REGIONS = DENSE_THREADS / WAVE;
+/* Expands the items parked by REGIONS consecutive waves of the dense kernel: THREADS threads take
+ * THREADS items per round, a block-wide prefix sum of the per-item record counts gives every item
+ * its slot, and ONE global atomic per round reserves the records (a single counter sustains only
+ * ~90 atomics per microsecond, so they are kept to a few hundred per launch).
+ * The launch leaves its own bookkeeping clean: each block zeroes the fill counters it consumed,
+ * and the block that finishes last hands the total to the caller's counter (when this is the
+ * last segment of a scan) and resets the running total and the ticket. */
+struct ExpandTail {
+  unsigned long long *user_count; /* where the caller wants the total */
+  unsigned int *ticket;
+  int last_segment;
+};
 
-template <bool CONT, bool COUNT_ONLY>
-__global__ __launch_bounds__ (EXPAND_THREADS) void
-expand_items_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, const uint32_t *fill) {
-  __shared__ uint32_t s_off[EXPAND_REGIONS + 1];
-  __shared__ uint32_t s_wave[EXPAND_THREADS / WAVE];
+template <bool CONT, bool COUNT_ONLY, int THREADS, int REGIONS>
+__global__ __launch_bounds__ (THREADS) void
+expand_items_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint32_t *fill, ExpandTail tail) {
+  __shared__ uint32_t s_off[REGIONS + 1];
+  __shared__ uint32_t s_wave[THREADS / WAVE];
   __shared__ unsigned long long s_base;
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   if (tid == 0) {
     uint32_t acc = 0;
-    for (int r = 0; r < EXPAND_REGIONS; r++) {
+    for (int r = 0; r < REGIONS; r++) {
       s_off[r] = acc;
-      acc += fill[blockIdx.x * EXPAND_REGIONS + r];
+      acc += fill[blockIdx.x * REGIONS + r];
+      fill[blockIdx.x * REGIONS + r] = 0;
     }
-    s_off[EXPAND_REGIONS] = acc;
+    s_off[REGIONS] = acc;
   }
   __syncthreads ();
-  const uint32_t total = s_off[EXPAND_REGIONS];
-  for (uint32_t base = 0; base < total; base += EXPAND_THREADS) {
+  const uint32_t total = s_off[REGIONS];
+  for (uint32_t base = 0; base < total; base += THREADS) {
     const uint32_t i = base + tid;
     const bool valid = i < total;
     uint2 it = make_uint2 (0, 0);
     if (valid) {
       uint32_t r = 0;
 #pragma unroll
-      for (int k = 1; k < EXPAND_REGIONS; k++)
+      for (int k = 1; k < REGIONS; k++)
         r += s_off[k] <= i ? 1u : 0u;
-      it = items[(size_t)(blockIdx.x * EXPAND_REGIONS + r) * region_items + (i - s_off[r])];
+      it = items[(size_t)(blockIdx.x * REGIONS + r) * region_items + (i - s_off[r])];
     }
     uint32_t own_cnt;
+    uint4 own_oi;
     ContResult res;
-    const uint32_t cnt = item_count<CONT> (E, valid, it, own_cnt, res);
+    const uint32_t cnt = item_count<CONT> (E, valid, it, own_cnt, own_oi, res);
     const uint32_t incl = wave_incl_scan (cnt);
     if (lane == WAVE - 1)
       s_wave[wid] = incl;
     __syncthreads ();
     if (tid == 0) {
       uint32_t acc = 0;
-      for (int k = 0; k < EXPAND_THREADS / WAVE; k++) {
+      for (int k = 0; k < THREADS / WAVE; k++) {
         const uint32_t v = s_wave[k];
         s_wave[k] = acc;
         acc += v;
@@ -358,8 +372,19 @@ expand_items_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, const
     }
     __syncthreads ();
     if (!COUNT_ONLY && cnt)
-      item_write<CONT> (E, it, own_cnt, res, s_base + s_wave[wid] + (incl - cnt));
+      item_write<CONT> (E, it, own_cnt, own_oi, res, s_base + s_wave[wid] + (incl - cnt));
     __syncthreads ();
+  }
+  if (tid == 0) {
+    __threadfence ();
+    if (atomicAdd (tail.ticket, 1u) == gridDim.x - 1) { /* every other block's adds are done */
+      __threadfence ();
+      *tail.ticket = 0;
+      if (tail.last_segment) {
+        *tail.user_count = atomicAdd (E.count, 0ull);
+        *E.count = 0;
+      }
+    }
   }
 }
 
@@ -787,19 +812,21 @@ struct ACMPlan {
   size_t blob_bytes = 0;
   /* CSR kernel (breadth-first numbering) */
   CsrTables csr{};
-  const uint32_t *c_term_kw = nullptr, *c_out_link = nullptr, *c_depth = nullptr;
+  const uint4 *d_oinfo = nullptr;
+  const uint16_t *d_cont_dh = nullptr;
   /* dense kernel (breadth-first numbering too: the LDS rows are a breadth-first prefix) */
   DenseK K{};
   const void *d_dense = nullptr;     /* failure-resolved rows of every state */
   const void *d_lds_image = nullptr; /* what every workgroup copies into LDS */
   const uint32_t *d_wrows = nullptr;
   const uint32_t *d_dstart = nullptr;
-  const uint16_t *d_hotfail = nullptr;
   uint32_t lds_image_bytes = 0;
   uint32_t entry_bytes = 0, streams = 2;
   /* item buffer of the dense kernel: regions x region_items items of 8 B, one region per wave */
   void *d_items = nullptr;
-  uint32_t *d_fill = nullptr;
+  uint32_t *d_fill = nullptr;   /* per region, zero between launches */
+  unsigned long long *d_total = nullptr; /* [0] running total of a scan, [1] low word = expand ticket; zero between scans */
+  int expand_cfg = 1;
   uint32_t regions = 0, region_items = 0;
   uint64_t generation = 0; /* for the machine-cached plan */
   int cu_count = 0;
@@ -896,6 +923,8 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   p->cu_count = prop.multiProcessorCount;
   if (const char *e = getenv ("ACM_GPU_STREAMS"))
     p->streams = atoi (e) == 4 ? 4 : 2;
+  if (const char *e = getenv ("ACM_GPU_EXPAND"))
+    p->expand_cfg = atoi (e) & 3;
 
   /* failure-resolved rows for byte alphabets whenever the whole DFA fits comfortably in HBM */
   const uint32_t n = fi.n_states;
@@ -937,12 +966,10 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const size_t o_next = blob_reserve (cur, (size_t)(fi.n_edges ? fi.n_edges : 1) * 4);
   const size_t o_fail = blob_reserve (cur, (size_t)n * 4);
   const size_t o_cnbo = blob_reserve (cur, (size_t)n * 4);
-  const size_t o_cterm = blob_reserve (cur, (size_t)n * 4);
-  const size_t o_clink = blob_reserve (cur, (size_t)n * 4);
-  const size_t o_cdepth = blob_reserve (cur, (size_t)n * 4);
+  const size_t o_oinfo = blob_reserve (cur, (size_t)n * 16);
   const size_t dense_bytes = dense ? (size_t)n * rowbytes : 0;
   const size_t o_dense = blob_reserve (cur, dense_bytes + 16);
-  const size_t o_hotfail = blob_reserve (cur, cont ? (size_t)n * 2 : 0);
+  const size_t o_contdh = blob_reserve (cur, cont ? (size_t)n * 2 : 0);
   const size_t o_wrows = blob_reserve (cur, cont ? (size_t)n * fi.width * 4 : 0);
   const size_t o_dstart = blob_reserve (cur, ((size_t)fi.lmax + 2) * 4);
   const uint32_t rows_lds = dense ? ((HD * rowbytes + 15) & ~15u) : 0;
@@ -956,9 +983,17 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   memcpy (&host[o_next], fv.edge_next, (size_t)fi.n_edges * 4);
   memcpy (&host[o_fail], fv.fail, (size_t)n * 4);
   memcpy (&host[o_cnbo], fv.nb_outputs, (size_t)n * 4);
-  memcpy (&host[o_cterm], fv.term_kw, (size_t)n * 4);
-  memcpy (&host[o_clink], fv.out_link, (size_t)n * 4);
-  memcpy (&host[o_cdepth], fv.depth, (size_t)n * 4);
+  {
+    uint32_t *oi = reinterpret_cast<uint32_t *> (&host[o_oinfo]);
+    for (uint32_t s = 0; s < n; s++) {
+      const uint32_t nb = fv.nb_outputs[s];
+      const uint32_t t0 = fv.term_kw[s] != NONE ? s : fv.out_link[s];
+      oi[4 * s + 0] = nb;
+      oi[4 * s + 1] = nb ? fv.out_link[t0] : 0;
+      oi[4 * s + 2] = nb ? fv.depth[t0] : 0;
+      oi[4 * s + 3] = nb ? fv.term_kw[t0] : 0;
+    }
+  }
   memcpy (&host[o_dstart], fv.depth_start, ((size_t)fi.lmax + 2) * 4);
   if (dense) {
     int rc = acm_flat_dense_rows (flat, n, entry_bytes, &host[o_dense]);
@@ -973,7 +1008,9 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       uint32_t *wr = reinterpret_cast<uint32_t *> (&host[o_wrows]);
       for (size_t i = 0; i < (size_t)n * fi.width; i++)
         wr[i] = r16[i] | (fv.depth[r16[i] & 0x7FFFu] << 16);
-      memcpy (&host[o_hotfail], hotfail.data (), (size_t)n * 2);
+      uint16_t *cdh = reinterpret_cast<uint16_t *> (&host[o_contdh]);
+      for (uint32_t s = 0; s < n; s++)
+        cdh[s] = (uint16_t)fv.depth[hotfail[s]];
       memcpy (&host[o_image + rows_lds], hotfail.data () + HD, (size_t)(n - HD) * 2);
     }
   }
@@ -994,14 +1031,12 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   p->csr.fail = u32p (o_fail);
   p->csr.nb_outputs = u32p (o_cnbo);
   p->csr.lmax = fi.lmax;
-  p->c_term_kw = u32p (o_cterm);
-  p->c_out_link = u32p (o_clink);
-  p->c_depth = u32p (o_cdepth);
+  p->d_oinfo = reinterpret_cast<const uint4 *> (b + o_oinfo);
   p->entry_bytes = entry_bytes;
   if (dense) {
     p->d_dense = b + o_dense;
     p->d_lds_image = b + o_image;
-    p->d_hotfail = cont ? reinterpret_cast<const uint16_t *> (b + o_hotfail) : nullptr;
+    p->d_cont_dh = cont ? reinterpret_cast<const uint16_t *> (b + o_contdh) : nullptr;
     p->d_wrows = cont ? reinterpret_cast<const uint32_t *> (b + o_wrows) : nullptr;
     p->lds_image_bytes = image_bytes;
     DenseK &K = p->K;
@@ -1067,6 +1102,8 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
     (void)hipFree (plan->d_items);
   if (plan->d_fill)
     (void)hipFree (plan->d_fill);
+  if (plan->d_total)
+    (void)hipFree (plan->d_total);
   delete plan;
 }
 
@@ -1183,14 +1220,41 @@ ensure_item_buffer (ACMPlan *p, uint64_t n) {
     return ACM_GPU_E_NOMEM;
   if (hipMalloc (reinterpret_cast<void **> (&p->d_fill), (size_t)regions * 4) != hipSuccess)
     return ACM_GPU_E_NOMEM;
+  HIP_TRY (hipMemset (p->d_fill, 0, (size_t)regions * 4));
+  if (!p->d_total) {
+    if (hipMalloc (reinterpret_cast<void **> (&p->d_total), 16) != hipSuccess)
+      return ACM_GPU_E_NOMEM;
+    HIP_TRY (hipMemset (p->d_total, 0, 16));
+  }
   p->regions = regions;
   p->region_items = (uint32_t)per;
   return ACM_GPU_OK;
 }
 
+template <bool CONT, bool COUNT_ONLY, int THREADS, int REGIONS>
+void
+launch_expand (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, const ExpandTail &tail, hipStream_t st) {
+  const dim3 g ((regions_used + REGIONS - 1) / REGIONS);
+  hipLaunchKernelGGL ((expand_items_kernel<CONT, COUNT_ONLY, THREADS, REGIONS>), g, dim3 (THREADS), 0, st, E,
+                      static_cast<const uint2 *> (p->d_items), p->region_items, p->d_fill, tail);
+}
+
+template <bool CONT, bool COUNT_ONLY>
+void
+launch_expand_cfg (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, const ExpandTail &tail, hipStream_t st) {
+  switch (p->expand_cfg) {
+  case 0: launch_expand<CONT, COUNT_ONLY, 1024, 16> (p, E, regions_used, tail, st); break;
+  case 2: launch_expand<CONT, COUNT_ONLY, 512, 4> (p, E, regions_used, tail, st); break;
+  case 3: launch_expand<CONT, COUNT_ONLY, 256, 2> (p, E, regions_used, tail, st); break;
+  default: launch_expand<CONT, COUNT_ONLY, 1024, 8> (p, E, regions_used, tail, st); break;
+  }
+}
+
+/* scan kernel, then the expansion of what it parked; the caller's counter is written by the
+ * expansion of the last segment (no memsets: both kernels leave their bookkeeping zeroed) */
 template <bool COUNT_ONLY>
 int
-launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop) {
+launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop, uint64_t *d_count, bool last_segment) {
   const uint32_t TILE = WAVE * p->streams * DENSE_C;
   a.range_begin = 0;
   a.range_end = (uint32_t)(((uint64_t)a.n + TILE - 1) / TILE);
@@ -1199,19 +1263,20 @@ launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
   const uint32_t blocks_needed = (a.range_end + wpb - 1) / wpb;
   if (blocks_needed < grid)
     grid = blocks_needed;
-  HIP_TRY (hipMemsetAsync (p->d_fill, 0, (size_t)p->regions * 4, st));
   void *args[] = { &p->K, const_cast<EmitCtx *> (&E), &a, &p->d_dense, &p->d_lds_image, &p->lds_image_bytes, &a.text,
                    &p->d_items, &p->region_items, &p->d_fill, &p->d_dstart };
   HIP_TRY (hipLaunchKernel (dense_kernel_ptr (p->entry_bytes, p->streams, COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), args,
                             p->info.lds_bytes, st));
   if (stop)
     HIP_TRY (hipEventRecord (stop, st));
-  const dim3 eg (grid);
-  const uint2 *items = static_cast<const uint2 *> (p->d_items);
+  ExpandTail tail;
+  tail.user_count = reinterpret_cast<unsigned long long *> (d_count);
+  tail.ticket = reinterpret_cast<unsigned int *> (p->d_total + 1);
+  tail.last_segment = last_segment ? 1 : 0;
   if (p->entry_bytes == 2)
-    hipLaunchKernelGGL ((expand_items_kernel<true, COUNT_ONLY>), eg, dim3 (EXPAND_THREADS), 0, st, E, items, p->region_items, p->d_fill);
+    launch_expand_cfg<true, COUNT_ONLY> (p, E, grid * wpb, tail, st);
   else
-    hipLaunchKernelGGL ((expand_items_kernel<false, COUNT_ONLY>), eg, dim3 (EXPAND_THREADS), 0, st, E, items, p->region_items, p->d_fill);
+    launch_expand_cfg<false, COUNT_ONLY> (p, E, grid * wpb, tail, st);
   HIP_TRY (hipGetLastError ());
   return ACM_GPU_OK;
 }
@@ -1221,37 +1286,34 @@ int
 scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint64_t pos_base, ACMRecord *d_records,
            uint64_t capacity, uint64_t *d_count, hipStream_t st) {
   HIP_TRY (hipSetDevice (p->device));
-  HIP_TRY (hipMemsetAsync (d_count, 0, sizeof (uint64_t), st));
-  if (n == 0 || p->finfo.n_edges == 0)
-    return ACM_GPU_OK;
   const uint32_t sb = p->finfo.sym_bytes;
   const bool use_dense = p->info.kernel == 1 && (reinterpret_cast<uintptr_t> (d_text) & 15) == 0;
-  EmitCtx E{};
-  E.nb_outputs = p->csr.nb_outputs;
-  E.term_kw = p->c_term_kw;
-  E.out_link = p->c_out_link;
-  E.depth = p->c_depth;
-  E.records = d_records;
-  E.count = reinterpret_cast<unsigned long long *> (d_count);
-  E.capacity = COUNT_ONLY ? 0 : capacity;
-  E.wrows = p->d_wrows;
-  E.hotfail = p->d_hotfail;
-  E.W = p->K.W;
-  E.lo = p->K.lo;
-  E.span = p->K.span;
-
+  if (n == 0 || p->finfo.n_edges == 0 || emit_from >= n || !use_dense)
+    HIP_TRY (hipMemsetAsync (d_count, 0, sizeof (uint64_t), st));
+  if (n == 0 || p->finfo.n_edges == 0 || emit_from >= n)
+    return ACM_GPU_OK;
   if (use_dense) {
     int rc = ensure_item_buffer (p, n < SEGMENT ? n : SEGMENT);
     if (rc)
       return rc;
   }
+  EmitCtx E{};
+  E.oinfo = p->d_oinfo;
+  E.records = d_records;
+  E.count = use_dense ? p->d_total : reinterpret_cast<unsigned long long *> (d_count);
+  E.capacity = COUNT_ONLY ? 0 : capacity;
+  E.wrows = p->d_wrows;
+  E.cont_dh = p->d_cont_dh;
+  E.W = p->K.W;
+  E.lo = p->K.lo;
+  E.span = p->K.span;
+
   /* segments of at most SEGMENT symbols; each restarts from the root `halo` symbols early
    * (a multiple of 16 bytes so that the dense kernel keeps its alignment) */
   const uint64_t halo = p->finfo.lmax > 1 ? (((uint64_t)p->finfo.lmax - 1 + 15) / 16) * 16 : 0;
-  for (uint64_t seg = 0; seg < n; seg += SEGMENT) {
+  const uint64_t first_seg = emit_from / SEGMENT * SEGMENT; /* earlier segments have nothing to report */
+  for (uint64_t seg = first_seg; seg < n; seg += SEGMENT) {
     const uint64_t seg_end = seg + SEGMENT < n ? seg + SEGMENT : n;
-    if (seg_end <= emit_from)
-      continue; /* nothing to report from this segment */
     const uint64_t read_begin = seg > halo ? seg - halo : 0;
     Launch a{};
     a.text = static_cast<const unsigned char *> (d_text) + read_begin * sb;
@@ -1267,7 +1329,7 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     if (rc)
       return rc;
     if (use_dense)
-      rc = launch_dense<COUNT_ONLY> (p, E, a, st, stop);
+      rc = launch_dense<COUNT_ONLY> (p, E, a, st, stop, d_count, seg_end == n);
     else {
       a.range_begin = 0;
       a.range_end = a.n;
