@@ -67,7 +67,7 @@ EXPORTS = [
     "acm_flat_dense_rows", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_destroy",
     "acm_gpu_plan_info", "acm_gpu_scan_device", "acm_gpu_count_device", "acm_gpu_sort_tmp_bytes",
     "acm_gpu_sort_records_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
-    "acm_gpu_plan_timing_read", "acm_gpu_synth_text",
+    "acm_gpu_plan_timing_read", "acm_gpu_plan_status", "acm_gpu_synth_text",
 ]
 
 
@@ -139,6 +139,8 @@ def lib():
     L.acm_gpu_scan_host.argtypes = [vp, vp, u64, u64, u64, vp, u64, C.POINTER(u64)]
     L.acm_scan.restype = i32
     L.acm_scan.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    L.acm_gpu_plan_status.restype = i32
+    L.acm_gpu_plan_status.argtypes = [vp]
     L.acm_gpu_plan_timing.restype = i32
     L.acm_gpu_plan_timing.argtypes = [vp, i32]
     L.acm_gpu_plan_timing_read.restype = i32
@@ -393,7 +395,7 @@ class Plan:
                 cap = n
                 continue
             self.sort(rec, n)
-            torch.cuda.synchronize(text.device)
+            self.status()
             return np.frombuffer(rec[:n].cpu().numpy().tobytes(), dtype=RECORD_DTYPE).copy()
 
     def scan_host(self, text, emit_from=0, pos_base=0, capacity=None):
@@ -411,6 +413,10 @@ class Plan:
                 continue
             _check(rc, "acm_gpu_scan_host")
             return out[:n.value]
+
+    def status(self):
+        """Synchronises and raises if a device-side consistency check failed."""
+        _check(lib().acm_gpu_plan_status(self.h), "acm_gpu_plan_status")
 
     def timing(self, enable=True):
         _check(lib().acm_gpu_plan_timing(self.h, 1 if enable else 0), "acm_gpu_plan_timing")

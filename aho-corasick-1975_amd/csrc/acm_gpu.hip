@@ -62,7 +62,7 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
 constexpr int QCAP = 128;           /* per-wave queue of (position, state) items, 8 B each */
 constexpr int DENSE_THREADS = 1024; /* one workgroup per CU, 16 waves */
-constexpr int DENSE_C = 64;         /* bytes per lane-stream per tile */
+/* dense kernel geometry: C = 64 bytes per lane-stream per tile, S = 2 streams per lane */
 constexpr uint64_t SEGMENT = 1ull << 31; /* symbols per launch: positions inside a launch are 32-bit */
 
 /* tables of the CSR kernel, states in breadth-first numbering (ACMFlatView) */
@@ -85,6 +85,9 @@ struct EmitCtx {
   const uint32_t *wrows;      /* continuation rows of every state: next | out flag << 15 | depth(next) << 16 */
   const uint16_t *cont_dh;    /* per state: depth of the nearest failure-chain state whose row is in LDS */
   uint32_t W, lo, span, n, emit_from;
+  uint32_t chunk; /* bytes per lane-stream chunk of the dense kernel (a power of two) */
+  uint32_t n_states;
+  unsigned int *error; /* set to 1 if an item with an impossible state id is ever met (never expected) */
 };
 
 /* one launch: a segment of the buffer, positions relative to its first symbol */
@@ -100,6 +103,7 @@ struct DenseK {
   uint32_t W, rowbytes, lo, span;
   uint32_t HD; /* states [0, HD): failure-resolved row in LDS */
   uint32_t aux_off, queue_off, wub, lmax;
+  uint32_t stream_stride; /* 64 * C: distance between the chunks of a lane's consecutive streams */
 };
 
 /* queue item, second word, when the dense kernel runs in continuation mode (16-bit states) */
@@ -176,8 +180,8 @@ struct ContResult {
  * One dependent load per symbol: the row entry carries the next state, its output flag and its
  * depth; the text byte of the following step is fetched alongside. */
 __device__ __forceinline__ uint32_t
-item_chunk_end (uint2 it) {
-  return (it.y & IT_RUN) ? it.x + 1 - ((it.y >> IT_K_SHIFT) & 0xFFFu) : (it.x | (DENSE_C - 1)) + 1;
+item_chunk_end (const EmitCtx &E, uint2 it) {
+  return (it.y & IT_RUN) ? it.x + 1 - ((it.y >> IT_K_SHIFT) & 0xFFFu) : (it.x | (E.chunk - 1)) + 1;
 }
 
 template <bool WRITE>
@@ -186,7 +190,7 @@ walk_continuation (const EmitCtx &E, uint2 it, uint64_t o) {
   ContResult r = { 0, 0, 0, 0, make_uint4 (0, 0, 0, 0) };
   const uint32_t pos = it.x, st = it.y & IT_STATE;
   const uint32_t dh = E.cont_dh[st];
-  const uint32_t ce = item_chunk_end (it);
+  const uint32_t ce = item_chunk_end (E, it);
   uint32_t s2 = st;
   uint32_t byte = pos + 1 < E.n ? E.text[pos + 1] : 0;
   for (uint32_t j = 1; pos + j < E.n; j++) {
@@ -220,6 +224,11 @@ template <bool CONT>
 __device__ __forceinline__ uint32_t
 item_count (const EmitCtx &E, bool valid, uint2 it, uint32_t &own_cnt, uint4 &own_oi, ContResult &r) {
   const uint32_t st = CONT ? (it.y & IT_STATE) : it.y;
+  if (valid && st >= E.n_states) { /* cannot happen; never index the tables with it */
+    if (E.error)
+      *E.error = 1;
+    valid = false;
+  }
   const bool own = valid && (!CONT || (it.y & IT_OUT));
   own_cnt = 0;
   own_oi = make_uint4 (0, 0, 0, 0);
@@ -446,7 +455,7 @@ dense_step_slow (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t
   bool rowless = false;
 #pragma unroll
   for (int q = 0; q < S; q++) {
-    const uint32_t pos = at.pos0 + (uint32_t)q * (WAVE * DENSE_C);
+    const uint32_t pos = at.pos0 + (uint32_t)q * K.stream_stride;
     if (!CONT && w.s[q] >= K.HD) /* sticky mode: the LDS lookup was meaningless, redo it from HBM */
       e[q] = gdense[w.s[q] * K.W + cls[q]];
     uint32_t ns = e[q] & IDMASK;
@@ -576,11 +585,7 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
   w.spill.fill = 0;
   DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_text = 0, d_tiles = 0;)
 
-  static_assert (NB == 4, "the software pipeline below is written for 4 blocks per chunk");
-  /* text registers: d[k][q] = block k of stream q's chunk, post[q] = the 16 bytes after it.
-   * Software pipeline without extra registers: as soon as a block has been walked its registers
-   * receive the same block of the wave's NEXT tile, so every load has at least half a tile of
-   * walking (thousands of cycles) to land. */
+  static_assert (NB == 2 || NB == 4, "the software pipeline below handles 2 or 4 blocks per chunk");
   uint4 d[NB][S], post[S];
   auto load_block = [&] (uint32_t p0, int k, int q) -> uint4 {
     const uint32_t off = p0 + q * (WAVE * C) + 16 * k;
@@ -629,22 +634,19 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
             w.s[q] = 0;
       }
     }
-    {
-      const StepAt a0 = { pos0, 0, 0, PH_MAIN }, a1 = { pos0 + 16, 0, 0, PH_MAIN };
-      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[0], a0, lane);
-      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[1], a1, lane);
+    /* first half of the chunk, refill its registers from the next tile, second half, refill */
 #pragma unroll
-      for (int q = 0; q < S; q++) {
-        d[0][q] = load_block (npos0, 0, q);
-        d[1][q] = load_block (npos0, 1, q);
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+      for (int k = h * (NB / 2); k < (h + 1) * (NB / 2); k++) {
+        const StepAt at = { pos0 + 16 * k, 0, 0, PH_MAIN };
+        dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[k], at, lane);
       }
-      const StepAt a2 = { pos0 + 32, 0, 0, PH_MAIN }, a3 = { pos0 + 48, 0, 0, PH_MAIN };
-      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[2], a2, lane);
-      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[3], a3, lane);
 #pragma unroll
-      for (int q = 0; q < S; q++) {
-        d[2][q] = load_block (npos0, 2, q);
-        d[3][q] = load_block (npos0, 3, q);
+      for (int k = h * (NB / 2); k < (h + 1) * (NB / 2); k++) {
+#pragma unroll
+        for (int q = 0; q < S; q++)
+          d[k][q] = load_block (npos0, k, q);
       }
     }
     if (CONT) {
@@ -821,12 +823,11 @@ struct ACMPlan {
   const uint32_t *d_wrows = nullptr;
   const uint32_t *d_dstart = nullptr;
   uint32_t lds_image_bytes = 0;
-  uint32_t entry_bytes = 0, streams = 2;
+  uint32_t entry_bytes = 0, streams = 2, chunk = 64;
   /* item buffer of the dense kernel: regions x region_items items of 8 B, one region per wave */
   void *d_items = nullptr;
   uint32_t *d_fill = nullptr;   /* per region, zero between launches */
   unsigned long long *d_total = nullptr; /* [0] running total of a scan, [1] low word = expand ticket; zero between scans */
-  int expand_cfg = 1;
   uint32_t regions = 0, region_items = 0;
   uint64_t generation = 0; /* for the machine-cached plan */
   int cu_count = 0;
@@ -848,6 +849,7 @@ acm_gpu_strerror (int code) {
   case ACM_GPU_E_OVERFLOW: return "record buffer too small";
   case ACM_GPU_E_ARG: return "invalid argument";
   case ACM_GPU_E_NOMEM: return "out of memory";
+  case ACM_GPU_E_INTERNAL: return "internal consistency check failed on the device";
   default: return "unknown error";
   }
 }
@@ -870,22 +872,20 @@ blob_reserve (size_t &cursor, size_t bytes) {
   return at;
 }
 
-template <typename ENTRY, int S, bool CO>
+template <typename ENTRY, int C, int S, bool CO>
 const void *
 dense_fn () {
-  return reinterpret_cast<const void *> (&scan_dense_kernel<ENTRY, DENSE_C, S, CO>);
+  return reinterpret_cast<const void *> (&scan_dense_kernel<ENTRY, C, S, CO>);
 }
 
+/* one geometry is built: 64-byte chunks, 2 streams per lane (the template takes others) */
 const void *
-dense_kernel_ptr (uint32_t entry_bytes, uint32_t streams, bool count_only) {
-  if (entry_bytes == 2) {
-    if (streams == 4)
-      return count_only ? dense_fn<uint16_t, 4, true> () : dense_fn<uint16_t, 4, false> ();
-    return count_only ? dense_fn<uint16_t, 2, true> () : dense_fn<uint16_t, 2, false> ();
-  }
-  if (streams == 4)
-    return count_only ? dense_fn<uint32_t, 4, true> () : dense_fn<uint32_t, 4, false> ();
-  return count_only ? dense_fn<uint32_t, 2, true> () : dense_fn<uint32_t, 2, false> ();
+dense_kernel_ptr (uint32_t entry_bytes, uint32_t chunk, uint32_t streams, bool count_only) {
+  (void)chunk;
+  (void)streams;
+  if (entry_bytes == 2)
+    return count_only ? dense_fn<uint16_t, 64, 2, true> () : dense_fn<uint16_t, 64, 2, false> ();
+  return count_only ? dense_fn<uint32_t, 64, 2, true> () : dense_fn<uint32_t, 64, 2, false> ();
 }
 
 void
@@ -921,10 +921,6 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   p->device = device;
   p->finfo = fi;
   p->cu_count = prop.multiProcessorCount;
-  if (const char *e = getenv ("ACM_GPU_STREAMS"))
-    p->streams = atoi (e) == 4 ? 4 : 2;
-  if (const char *e = getenv ("ACM_GPU_EXPAND"))
-    p->expand_cfg = atoi (e) & 3;
 
   /* failure-resolved rows for byte alphabets whenever the whole DFA fits comfortably in HBM */
   const uint32_t n = fi.n_states;
@@ -1049,6 +1045,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     K.queue_off = image_bytes;
     K.wub = fi.lmax > 1 ? (fi.lmax - 1 + 15) / 16 : 0;
     K.lmax = fi.lmax;
+    K.stream_stride = WAVE * p->chunk;
   }
   p->d_dstart = u32p (o_dstart);
 
@@ -1063,13 +1060,13 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   I.lds_bytes = dense ? image_bytes + queue_bytes : QCAP * 8;
   I.block_threads = dense ? DENSE_THREADS : WAVE;
   I.grid_blocks = dense ? (uint32_t)p->cu_count : (uint32_t)p->cu_count * 16;
-  I.chunk_bytes = DENSE_C;
+  I.chunk_bytes = p->chunk;
   I.streams = p->streams;
   I.table_bytes = cur;
 
   if (dense) {
     for (int co = 0; co < 2; co++)
-      HIP_TRY (hipFuncSetAttribute (dense_kernel_ptr (entry_bytes, p->streams, co != 0),
+      HIP_TRY (hipFuncSetAttribute (dense_kernel_ptr (entry_bytes, p->chunk, p->streams, co != 0),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)I.lds_bytes));
   }
   *out = p;
@@ -1110,6 +1107,19 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
 extern "C" void
 acm_gpu_plan_info (const ACMPlan *plan, ACMPlanInfo *info) {
   *info = plan->info;
+}
+
+extern "C" int
+acm_gpu_plan_status (ACMPlan *plan) {
+  if (!plan)
+    return ACM_GPU_E_ARG;
+  HIP_TRY (hipSetDevice (plan->device));
+  HIP_TRY (hipDeviceSynchronize ());
+  if (!plan->d_total)
+    return ACM_GPU_OK;
+  unsigned int words[4] = { 0, 0, 0, 0 };
+  HIP_TRY (hipMemcpy (words, plan->d_total, sizeof words, hipMemcpyDeviceToHost));
+  return words[3] ? ACM_GPU_E_INTERNAL : ACM_GPU_OK;
 }
 
 extern "C" int
@@ -1242,12 +1252,9 @@ launch_expand (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, const Expand
 template <bool CONT, bool COUNT_ONLY>
 void
 launch_expand_cfg (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, const ExpandTail &tail, hipStream_t st) {
-  switch (p->expand_cfg) {
-  case 0: launch_expand<CONT, COUNT_ONLY, 1024, 16> (p, E, regions_used, tail, st); break;
-  case 2: launch_expand<CONT, COUNT_ONLY, 512, 4> (p, E, regions_used, tail, st); break;
-  case 3: launch_expand<CONT, COUNT_ONLY, 256, 2> (p, E, regions_used, tail, st); break;
-  default: launch_expand<CONT, COUNT_ONLY, 1024, 8> (p, E, regions_used, tail, st); break;
-  }
+  /* 1024 threads per 8 regions measured best (fewer, larger blocks: too few items in flight;
+   * more, smaller blocks: the single record counter's atomic rate becomes the limit) */
+  launch_expand<CONT, COUNT_ONLY, 1024, 8> (p, E, regions_used, tail, st);
 }
 
 /* scan kernel, then the expansion of what it parked; the caller's counter is written by the
@@ -1255,7 +1262,7 @@ launch_expand_cfg (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, const Ex
 template <bool COUNT_ONLY>
 int
 launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop, uint64_t *d_count, bool last_segment) {
-  const uint32_t TILE = WAVE * p->streams * DENSE_C;
+  const uint32_t TILE = WAVE * p->streams * p->chunk;
   a.range_begin = 0;
   a.range_end = (uint32_t)(((uint64_t)a.n + TILE - 1) / TILE);
   uint32_t grid = p->info.grid_blocks;
@@ -1265,7 +1272,7 @@ launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
     grid = blocks_needed;
   void *args[] = { &p->K, const_cast<EmitCtx *> (&E), &a, &p->d_dense, &p->d_lds_image, &p->lds_image_bytes, &a.text,
                    &p->d_items, &p->region_items, &p->d_fill, &p->d_dstart };
-  HIP_TRY (hipLaunchKernel (dense_kernel_ptr (p->entry_bytes, p->streams, COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), args,
+  HIP_TRY (hipLaunchKernel (dense_kernel_ptr (p->entry_bytes, p->chunk, p->streams, COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), args,
                             p->info.lds_bytes, st));
   if (stop)
     HIP_TRY (hipEventRecord (stop, st));
@@ -1307,6 +1314,9 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   E.W = p->K.W;
   E.lo = p->K.lo;
   E.span = p->K.span;
+  E.chunk = p->chunk;
+  E.n_states = p->finfo.n_states;
+  E.error = p->d_total ? reinterpret_cast<unsigned int *> (p->d_total) + 3 : nullptr;
 
   /* segments of at most SEGMENT symbols; each restarts from the root `halo` symbols early
    * (a multiple of 16 bytes so that the dense kernel keeps its alignment) */

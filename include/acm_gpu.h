@@ -44,7 +44,8 @@ enum {
   ACM_GPU_E_HIP = -3,        /* a HIP call failed (message on stderr) */
   ACM_GPU_E_OVERFLOW = -4,   /* more matches than `capacity`; the count output holds the number needed */
   ACM_GPU_E_ARG = -5,        /* invalid argument */
-  ACM_GPU_E_NOMEM = -6
+  ACM_GPU_E_NOMEM = -6,
+  ACM_GPU_E_INTERNAL = -7    /* a device-side consistency check failed (never expected) */
 };
 const char *acm_gpu_strerror (int code);
 int acm_gpu_device_count (void);
@@ -150,6 +151,10 @@ int acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint
  * when the dictionary changed since the last call.  Device = $ACM_GPU_DEVICE or 0. */
 int acm_scan (ACMachine *machine, const void *text, uint64_t n_symbols, ACMRecord *records,
               uint64_t capacity, uint64_t *n_found);
+
+/* Waits for the plan's device and reports ACM_GPU_E_INTERNAL if a device-side consistency check
+ * ever failed during its scans (never expected), else ACM_GPU_OK. */
+int acm_gpu_plan_status (ACMPlan *plan);
 
 /* Kernel timing with HIP events recorded on the launch stream around the scan kernel only.
  * Enable, run scans, then read: total milliseconds and number of launches since enabling.
