@@ -62,7 +62,11 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
 constexpr int QCAP = 128;           /* per-wave queue of (position, state) items, 8 B each */
 constexpr int DENSE_THREADS = 1024; /* one workgroup per CU, 16 waves */
-/* dense kernel geometry: C = 64 bytes per lane-stream per tile, S = 2 streams per lane */
+/* dense kernel geometry: C = 64 bytes per lane-stream per tile, S = 2 streams per lane
+ * (-DACM_DENSE_S=n builds another stream count for experiments: 3 and 4 spill and are 2x slower) */
+#ifndef ACM_DENSE_S
+#define ACM_DENSE_S 2
+#endif
 constexpr uint64_t SEGMENT = 1ull << 31; /* symbols per launch: positions inside a launch are 32-bit */
 
 /* tables of the CSR kernel, states in breadth-first numbering (ACMFlatView) */
@@ -340,12 +344,17 @@ expand_items_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint3
   __shared__ uint32_t s_wave[THREADS / WAVE];
   __shared__ unsigned long long s_base;
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  if (tid < REGIONS) { /* fill counters of this block's regions: read and zero them in parallel */
+    s_off[tid + 1] = fill[blockIdx.x * REGIONS + tid];
+    fill[blockIdx.x * REGIONS + tid] = 0;
+  }
+  __syncthreads ();
   if (tid == 0) {
     uint32_t acc = 0;
     for (int r = 0; r < REGIONS; r++) {
+      const uint32_t v = s_off[r + 1];
       s_off[r] = acc;
-      acc += fill[blockIdx.x * REGIONS + r];
-      fill[blockIdx.x * REGIONS + r] = 0;
+      acc += v;
     }
     s_off[REGIONS] = acc;
   }
@@ -385,9 +394,9 @@ expand_items_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint3
     __syncthreads ();
   }
   if (tid == 0) {
-    __threadfence ();
-    if (atomicAdd (tail.ticket, 1u) == gridDim.x - 1) { /* every other block's adds are done */
-      __threadfence ();
+    /* this block's adds to the running total have returned (their values were used), so the block
+     * that draws the last ticket sees every add */
+    if (atomicAdd (tail.ticket, 1u) == gridDim.x - 1) {
       *tail.ticket = 0;
       if (tail.last_segment) {
         *tail.user_count = atomicAdd (E.count, 0ull);
@@ -823,7 +832,7 @@ struct ACMPlan {
   const uint32_t *d_wrows = nullptr;
   const uint32_t *d_dstart = nullptr;
   uint32_t lds_image_bytes = 0;
-  uint32_t entry_bytes = 0, streams = 2, chunk = 64;
+  uint32_t entry_bytes = 0, streams = ACM_DENSE_S, chunk = 64;
   /* item buffer of the dense kernel: regions x region_items items of 8 B, one region per wave */
   void *d_items = nullptr;
   uint32_t *d_fill = nullptr;   /* per region, zero between launches */
@@ -884,8 +893,8 @@ dense_kernel_ptr (uint32_t entry_bytes, uint32_t chunk, uint32_t streams, bool c
   (void)chunk;
   (void)streams;
   if (entry_bytes == 2)
-    return count_only ? dense_fn<uint16_t, 64, 2, true> () : dense_fn<uint16_t, 64, 2, false> ();
-  return count_only ? dense_fn<uint32_t, 64, 2, true> () : dense_fn<uint32_t, 64, 2, false> ();
+    return count_only ? dense_fn<uint16_t, 64, ACM_DENSE_S, true> () : dense_fn<uint16_t, 64, ACM_DENSE_S, false> ();
+  return count_only ? dense_fn<uint32_t, 64, ACM_DENSE_S, true> () : dense_fn<uint32_t, 64, ACM_DENSE_S, false> ();
 }
 
 void
