@@ -68,6 +68,7 @@ constexpr int DENSE_THREADS = 1024; /* one workgroup per CU, 16 waves */
 #define ACM_DENSE_S 2
 #endif
 constexpr uint64_t SEGMENT = 1ull << 31; /* symbols per launch: positions inside a launch are 32-bit */
+/* tests shrink it with ACM_GPU_SEGMENT_LOG2 to cross segment seams on small inputs */
 
 /* tables of the CSR kernel, states in breadth-first numbering (ACMFlatView) */
 struct CsrTables {
@@ -462,30 +463,39 @@ dense_step_slow (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t
   constexpr uint32_t IDMASK = FLAG - 1;
   constexpr bool CONT = EntryTraits<ENTRY>::CONT;
   bool rowless = false;
+  uint32_t ns[S], carry[S];
+  /* first all the loads, so that their latencies overlap with the queue bookkeeping below */
+#pragma unroll
+  for (int q = 0; q < S; q++) {
+    if (!CONT && w.s[q] >= K.HD) /* sticky mode: the LDS lookup was meaningless, redo it from HBM */
+      e[q] = gdense[w.s[q] * K.W + cls[q]];
+  }
+#pragma unroll
+  for (int q = 0; q < S; q++) {
+    ns[q] = e[q] & IDMASK;
+    carry[q] = ns[q];
+    if (CONT && ns[q] >= K.HD) /* the lane carries on from the nearest state that has a row */
+      carry[q] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint16_t *> (K.aux_off + (ns[q] - K.HD) * 2u);
+  }
 #pragma unroll
   for (int q = 0; q < S; q++) {
     const uint32_t pos = at.pos0 + (uint32_t)q * K.stream_stride;
-    if (!CONT && w.s[q] >= K.HD) /* sticky mode: the LDS lookup was meaningless, redo it from HBM */
-      e[q] = gdense[w.s[q] * K.W + cls[q]];
-    uint32_t ns = e[q] & IDMASK;
     const bool window = pos >= emit_from && pos < emit_end;
     if (CONT) {
       /* run-over: a lane whose state is no deeper than k has nothing of its own left */
-      const bool live = at.phase != PH_RUN || ns >= at.live_from;
+      const bool live = at.phase != PH_RUN || ns[q] >= at.live_from;
       const bool out = live && (e[q] & FLAG) && window;
-      const bool deep = live && ns >= K.HD && pos < emit_end;
-      uint32_t word = ns | (deep ? IT_CONT : 0u) | (out ? IT_OUT : 0u);
+      const bool deep = live && ns[q] >= K.HD && pos < emit_end;
+      uint32_t word = ns[q] | (deep ? IT_CONT : 0u) | (out ? IT_OUT : 0u);
       if (at.phase == PH_RUN)
         word |= IT_RUN | (at.k << IT_K_SHIFT);
       queue_push<CONT, COUNT_ONLY> (E, queue, w.qn, out | deep, pos, word, lane, &w.spill);
-      if (ns >= K.HD)
-        ns = *reinterpret_cast<const __attribute__ ((address_space (3))) uint16_t *> (K.aux_off + (ns - K.HD) * 2u);
     } else {
       const bool out = at.phase == PH_MAIN && (e[q] & FLAG) && window;
-      queue_push<CONT, COUNT_ONLY> (E, queue, w.qn, out, pos, ns, lane, &w.spill);
-      rowless |= ns >= K.HD;
+      queue_push<CONT, COUNT_ONLY> (E, queue, w.qn, out, pos, ns[q], lane, &w.spill);
+      rowless |= ns[q] >= K.HD;
     }
-    w.s[q] = ns;
+    w.s[q] = carry[q];
   }
   if (!CONT)
     w.sticky = rowless ? ~0u : 0u;
@@ -838,6 +848,7 @@ struct ACMPlan {
   uint32_t *d_fill = nullptr;   /* per region, zero between launches */
   unsigned long long *d_total = nullptr; /* [0] running total of a scan, [1] low word = expand ticket; zero between scans */
   uint32_t regions = 0, region_items = 0;
+  uint64_t segment = SEGMENT;
   uint64_t generation = 0; /* for the machine-cached plan */
   int cu_count = 0;
   /* timing */
@@ -931,6 +942,11 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   p->finfo = fi;
   p->cu_count = prop.multiProcessorCount;
 
+  if (const char *e = getenv ("ACM_GPU_SEGMENT_LOG2")) {
+    const int lg = atoi (e);
+    if (lg >= 12 && lg <= 31)
+      p->segment = 1ull << lg;
+  }
   /* failure-resolved rows for byte alphabets whenever the whole DFA fits comfortably in HBM */
   const uint32_t n = fi.n_states;
   const uint32_t entry_bytes = n <= 32768 ? 2 : 4;
@@ -1309,7 +1325,7 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   if (n == 0 || p->finfo.n_edges == 0 || emit_from >= n)
     return ACM_GPU_OK;
   if (use_dense) {
-    int rc = ensure_item_buffer (p, n < SEGMENT ? n : SEGMENT);
+    int rc = ensure_item_buffer (p, n < p->segment ? n : p->segment);
     if (rc)
       return rc;
   }
@@ -1330,9 +1346,10 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   /* segments of at most SEGMENT symbols; each restarts from the root `halo` symbols early
    * (a multiple of 16 bytes so that the dense kernel keeps its alignment) */
   const uint64_t halo = p->finfo.lmax > 1 ? (((uint64_t)p->finfo.lmax - 1 + 15) / 16) * 16 : 0;
-  const uint64_t first_seg = emit_from / SEGMENT * SEGMENT; /* earlier segments have nothing to report */
-  for (uint64_t seg = first_seg; seg < n; seg += SEGMENT) {
-    const uint64_t seg_end = seg + SEGMENT < n ? seg + SEGMENT : n;
+  const uint64_t SEG = p->segment;
+  const uint64_t first_seg = emit_from / SEG * SEG; /* earlier segments have nothing to report */
+  for (uint64_t seg = first_seg; seg < n; seg += SEG) {
+    const uint64_t seg_end = seg + SEG < n ? seg + SEG : n;
     const uint64_t read_begin = seg > halo ? seg - halo : 0;
     Launch a{};
     a.text = static_cast<const unsigned char *> (d_text) + read_begin * sb;

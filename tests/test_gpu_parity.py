@@ -210,3 +210,29 @@ def test_100k_dictionary_config3_shape(torch_cuda):
     assert got.size == cnt and po.digest(got) == dig
     want_head = o.scan(text[:1 << 20])
     assert np.array_equal(got[got["end_pos"] < (1 << 20)], want_head)
+
+
+def test_segment_seams(torch_cuda, monkeypatch):
+    """Buffers longer than one launch segment (2^31 symbols) are scanned segment by segment with
+    an lmax-1 halo; exercised here with the segment shrunk to 64 KiB (and 4 KiB for the CSR
+    kernel) so that keywords straddle many seams."""
+    monkeypatch.setenv("ACM_GPU_SEGMENT_LOG2", "16")
+    kd, ko = acm.synth.keywords(300)
+    m, o = build_pair_packed(kd, ko)
+    n = 5 * 65536 + 777
+    text = acm.synth.text((n + 4095) // 4096 * 4096, kd, ko)[:n].copy()
+    for seam in range(65536, n, 65536):                 # a long and a short keyword across every seam
+        text[seam - 5:seam + 7] = np.frombuffer(bytes(kd[ko[7]:ko[8]]) * 3, np.uint8)[:12]
+    want = o.scan(text)
+    plan = m.plan(0)
+    assert np.array_equal(plan.scan_sorted(_dev(torch_cuda, text)), want)
+    cut = 3 * 65536 + 5
+    ref = want[want["end_pos"] >= cut]
+    assert np.array_equal(plan.scan_sorted(_dev(torch_cuda, text), emit_from=cut), ref)
+    assert int(plan.count(_dev(torch_cuda, text)).item()) == want.size
+    # CSR kernel (uint32 symbols) across seams
+    monkeypatch.setenv("ACM_GPU_SEGMENT_LOG2", "12")
+    kd4, ko4 = acm.synth.keywords(500, sym_bytes=4, vocab=300)
+    m4, o4 = build_pair_packed(kd4, ko4, sym_size=4)
+    t4 = acm.synth.text(5 * 4096, kd4, ko4, sym_bytes=4, vocab=300)[:5 * 4096 - 100]
+    assert np.array_equal(m4.plan(0).scan_sorted(_dev(torch_cuda, t4)), o4.scan(t4))
