@@ -653,20 +653,27 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
             w.s[q] = 0;
       }
     }
-    /* first half of the chunk, refill its registers from the next tile, second half, refill */
+    /* walk blocks 0 .. NB-2, refill their registers from the next tile, walk the last block,
+     * refill it.  (Refilling half and half re-touched every 128-byte line half a tile later, when
+     * part of them had already left L2: 1.37x the text in L2 misses.  Non-temporal loads were
+     * 1.55x slower for the same reason.) */
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int k = 0; k < NB - 1; k++) {
+      const StepAt at = { pos0 + 16 * k, 0, 0, PH_MAIN };
+      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[k], at, lane);
+    }
 #pragma unroll
-      for (int k = h * (NB / 2); k < (h + 1) * (NB / 2); k++) {
-        const StepAt at = { pos0 + 16 * k, 0, 0, PH_MAIN };
-        dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[k], at, lane);
-      }
+    for (int k = 0; k < NB - 1; k++) {
 #pragma unroll
-      for (int k = h * (NB / 2); k < (h + 1) * (NB / 2); k++) {
+      for (int q = 0; q < S; q++)
+        d[k][q] = load_block (npos0, k, q);
+    }
+    {
+      const StepAt at = { pos0 + 16 * (NB - 1), 0, 0, PH_MAIN };
+      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[NB - 1], at, lane);
 #pragma unroll
-        for (int q = 0; q < S; q++)
-          d[k][q] = load_block (npos0, k, q);
-      }
+      for (int q = 0; q < S; q++)
+        d[NB - 1][q] = load_block (npos0, NB - 1, q);
     }
     if (CONT) {
       /* continuation mode, ownership by START position: run over into the following bytes until
