@@ -28,13 +28,16 @@ def gather_records(local, group=None, dst=0):
     Returns on `dst` the concatenation over ranks in rank order, elsewhere None."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    out_dev = local.device
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        local = local.cpu()        # gloo moves host memory only (CPU tests, 1-GPU rehearsals)
     dev = local.device
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)
     counts = [int(c.item()) for c in counts]
     if world == 1:
-        return local
+        return local.to(out_dev)
     if rank == dst:
         total = sum(counts)
         out = torch.empty((total, 2), dtype=torch.int64, device=dev)
@@ -49,7 +52,7 @@ def gather_records(local, group=None, dst=0):
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        return out
+        return out.to(out_dev)
     if counts[rank]:
         for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), _global_rank(dst, group), group)]):
             req.wait()

@@ -46,10 +46,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU scan path"
+    # BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- lets the N>1 code path be
+    # exercised on a one-GPU box (numbers from such a run mean nothing and say so)
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- dictionary + plan (host build is not on the metric)
     kd, ko = acm.synth.keywords(args.keywords)
@@ -78,6 +86,7 @@ def main():
         plan.scan(text, n_scan, emit_from=halo, pos_base=pos_base, records=records, count=count)
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -96,11 +105,12 @@ def main():
     n_matches = int(count.item())
     assert n_matches <= cap, "record buffer overflow (%d > %d)" % (n_matches, cap)
 
+    cdev = torch.device("cpu") if rehearsal else dev
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([n_matches], dtype=torch.int64, device=dev)
+        tot = torch.tensor([n_matches], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         total_matches = int(tot.item())
     else:
@@ -125,7 +135,7 @@ def main():
     barrier()
     e2e_elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([e2e_elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([e2e_elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e2e_elapsed = float(t.item())
 
@@ -150,7 +160,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo; numbers meaningless)" if rehearsal else ""),
             "config": {
                 "workload": "BASELINE configs[1]: %d ASCII keywords (len 4-12), %d MiB synthetic a-z text per GPU, "
                             "1 keyword planted per 4096 B" % (args.keywords, args.mib),
