@@ -148,6 +148,13 @@ def main():
         algo_bytes = float(n_own) + 16.0 * n_matches        # 1 B per symbol read + 16 B per record
         achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
         info = plan.describe()
+        # HBM bytes per launch of the scan kernel from the PMC passes of the same command
+        # (tools/collect_profiles.sh -> profiles/traffic_latest.json); counters cannot be read in-process
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath) and args.keywords == 1000 and args.mib == 1024:
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
         out = {
             "metric": "input GB/s scanned, 1k-keyword dictionary, bit-exact match set",
             "value": round(value, 3),
@@ -173,7 +180,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction)" if traffic else None,
                 "kernel": "scan_dense_kernel", "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": kern_launches,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
