@@ -604,7 +604,7 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
   w.spill.fill = 0;
   DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_text = 0, d_tiles = 0;)
 
-  static_assert (NB == 2 || NB == 4, "the software pipeline below handles 2 or 4 blocks per chunk");
+  static_assert (NB == 4, "the software pipeline below is written out for 4 blocks per chunk");
   uint4 d[NB][S], post[S];
   auto load_block = [&] (uint32_t p0, int k, int q) -> uint4 {
     const uint32_t off = p0 + q * (WAVE * C) + 16 * k;
@@ -614,9 +614,10 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
     const uint32_t p0 = (A.range_begin + wave) * TILE + lane * C;
 #pragma unroll
     for (int q = 0; q < S; q++) {
-#pragma unroll
-      for (int k = 0; k < NB; k++)
-        d[k][q] = load_block (p0, k, q);
+      d[0][q] = load_block (p0, 0, q);
+      d[1][q] = load_block (p0, 1, q);
+      d[2][q] = load_block (p0, 2, q);
+      d[3][q] = load_block (p0, 3, q);
       post[q] = load_block (p0, NB, q);
     }
   }
@@ -657,24 +658,25 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
      * refill it.  (Refilling half and half re-touched every 128-byte line half a tile later, when
      * part of them had already left L2: 1.37x the text in L2 misses.  Non-temporal loads were
      * 1.55x slower for the same reason.) */
-#pragma unroll
-    for (int k = 0; k < NB - 1; k++) {
-      const StepAt at = { pos0 + 16 * k, 0, 0, PH_MAIN };
-      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[k], at, lane);
-    }
-#pragma unroll
-    for (int k = 0; k < NB - 1; k++) {
-#pragma unroll
-      for (int q = 0; q < S; q++)
-        d[k][q] = load_block (npos0, k, q);
-    }
-    {
-      const StepAt at = { pos0 + 16 * (NB - 1), 0, 0, PH_MAIN };
-      dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[NB - 1], at, lane);
-#pragma unroll
-      for (int q = 0; q < S; q++)
-        d[NB - 1][q] = load_block (npos0, NB - 1, q);
-    }
+    /* (written out block by block: a loop over k that the compiler declines to unroll would index
+     * the text registers dynamically and push them into scratch memory) */
+#define ACM_WALK_BLOCK(k)                                                                          \
+  {                                                                                                \
+    const StepAt at_ = { pos0 + 16 * (k), 0, 0, PH_MAIN };                                         \
+    dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[k], at_, lane); \
+  }
+#define ACM_REFILL_BLOCK(k)                                                                        \
+  _Pragma ("unroll") for (int q = 0; q < S; q++) d[k][q] = load_block (npos0, k, q);
+    ACM_WALK_BLOCK (0)
+    ACM_WALK_BLOCK (1)
+    ACM_WALK_BLOCK (2)
+    ACM_REFILL_BLOCK (0)
+    ACM_REFILL_BLOCK (1)
+    ACM_REFILL_BLOCK (2)
+    ACM_WALK_BLOCK (3)
+    ACM_REFILL_BLOCK (3)
+#undef ACM_WALK_BLOCK
+#undef ACM_REFILL_BLOCK
     if (CONT) {
       /* continuation mode, ownership by START position: run over into the following bytes until
        * no lane's state is deeper than the number of bytes past its chunk (at most lmax - 1) */

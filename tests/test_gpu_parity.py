@@ -236,3 +236,73 @@ def test_segment_seams(torch_cuda, monkeypatch):
     m4, o4 = build_pair_packed(kd4, ko4, sym_size=4)
     t4 = acm.synth.text(5 * 4096, kd4, ko4, sym_bytes=4, vocab=300)[:5 * 4096 - 100]
     assert np.array_equal(m4.plan(0).scan_sorted(_dev(torch_cuda, t4)), o4.scan(t4))
+
+
+def _checksums(torch, rec, n):
+    """order-independent fingerprints of the first n records of an int64 [cap, 2] device buffer"""
+    r = rec[:n]
+    pos = r[:, 0]
+    length = r[:, 1] & 0xFFFFFFFF
+    kw = r[:, 1] >> 32
+    return (int(pos.sum().item()), int(length.sum().item()), int(kw.sum().item()),
+            int((pos * 1315423911 ^ (length << 40) ^ (kw + 1)).sum().item()))
+
+
+def _scan_whole_vs_shards(torch, plan, text, n, lmax, cap, shards=4):
+    rec = torch.empty((cap, 2), dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    plan.scan(text, n, records=rec, count=cnt)
+    whole_n = int(cnt.item())
+    assert whole_n <= cap
+    whole = _checksums(torch, rec, whole_n)
+    assert int(plan.count(text, n).item()) == whole_n
+    tot, sums = 0, [0, 0, 0, 0]
+    esz = text.element_size()
+    for r in range(shards):
+        b, e = n * r // shards, n * (r + 1) // shards
+        rb = max(b - (lmax - 1), 0)
+        plan.scan(text[rb:e], e - rb, emit_from=b - rb, pos_base=rb, records=rec, count=cnt)
+        k = int(cnt.item())
+        c = _checksums(torch, rec, k)
+        tot += k
+        sums = [(x + y) for x, y in zip(sums, c)]
+    plan.status()
+    assert tot == whole_n
+
+    def wrap(v):
+        return (v + (1 << 63)) % (1 << 64) - (1 << 63)
+    assert tuple(wrap(v) for v in sums) == tuple(wrap(v) for v in whole)
+    return whole_n
+
+
+def test_config3_full_size_properties(torch_cuda):
+    """BASELINE config 3 at full size (100k keywords, 16 GiB text): the record set of the whole
+    scan equals the union of four shard scans with lmax-1 warm-up (count and order-independent
+    checksums), and equals the count-only entry point.  The first 16 MiB are also compared with
+    the oracle in test_100k_dictionary_config3_shape."""
+    torch = torch_cuda
+    kd, ko = acm.synth.keywords(100000)
+    m = acm.Machine(1)
+    m.add_keywords_packed(kd, ko)
+    plan = m.plan(0)
+    n = 16 << 30
+    text = acm.synth.device_text(n, kd, ko)
+    found = _scan_whole_vs_shards(torch, plan, text, n, m.lmax, cap=600_000_000)
+    assert found > 400_000_000          # ~28 M matches per GiB (SURVEY.md 8a)
+    del text
+    torch.cuda.empty_cache()
+
+
+def test_config5_full_size_properties(torch_cuda):
+    """BASELINE config 5 at full size (uint32 symbols, 10k keywords, 2^30 tokens = 4 GiB)."""
+    torch = torch_cuda
+    kd, ko = acm.synth.keywords(10000, sym_bytes=4)
+    m = acm.Machine(4)
+    m.add_keywords_packed(kd, ko)
+    plan = m.plan(0)
+    n = 1 << 30
+    text = acm.synth.device_text(n, kd, ko, sym_bytes=4)
+    found = _scan_whole_vs_shards(torch, plan, text, n, m.lmax, cap=4_000_000)
+    assert found >= (n // 4096)         # at least the planted keywords
+    del text
+    torch.cuda.empty_cache()
