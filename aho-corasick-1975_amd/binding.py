@@ -63,7 +63,7 @@ EXPORTS = [
     "ACM_CMP_DEFAULT", "ACM_INCREMENTAL_STRING_MATCHING", "acm_create", "acm_initiate",
     "acm_insert_letter_of_keyword", "acm_insert_end_of_keyword", "acm_match", "acm_matcher_init", "acm_get_match",
     "acm_matcher_release", "acm_nb_keywords", "acm_foreach_keyword", "acm_release", "acm_print",
-    "acm_gpu_strerror", "acm_gpu_device_count", "acm_flatten", "acm_flat_release", "acm_flat_info", "acm_flat_view",
+    "acm_gpu_strerror", "acm_gpu_device_count", "acm_get_keyword", "acm_flatten", "acm_flat_release", "acm_flat_info", "acm_flat_view",
     "acm_flat_dense_rows", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_destroy",
     "acm_gpu_plan_info", "acm_gpu_scan_device", "acm_gpu_count_device", "acm_gpu_sort_tmp_bytes",
     "acm_gpu_sort_records_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
@@ -109,6 +109,8 @@ def lib():
     L.acm_gpu_strerror.restype = C.c_char_p
     L.acm_gpu_strerror.argtypes = [i32]
     L.acm_gpu_device_count.restype = i32
+    L.acm_get_keyword.restype = i32
+    L.acm_get_keyword.argtypes = [vp, u32, C.POINTER(MatchHolder)]
     L.acm_flatten.restype = i32
     L.acm_flatten.argtypes = [vp, C.POINTER(vp)]
     L.acm_flat_release.restype = None
@@ -288,6 +290,17 @@ class Machine:
                 out.append((i, int(h.length), word, h.value))
         L.acm_matcher_release(C.byref(h))
         return out
+
+    def keyword(self, keyword_id):
+        """(symbols tuple, value pointer) of a keyword id, through acm_get_keyword."""
+        h = MatchHolder()
+        self.L.acm_matcher_init(C.byref(h))
+        _check(self.L.acm_get_keyword(self.handle, keyword_id, C.byref(h)), "acm_get_keyword")
+        ptr_t = C.POINTER({1: C.c_uint8, 2: C.c_uint16, 4: C.c_uint32, 8: C.c_uint64}[self.sym_size])
+        word = tuple(C.cast(h.letters[k], ptr_t)[0] for k in range(h.length))
+        value = h.value
+        self.L.acm_matcher_release(C.byref(h))
+        return word, value
 
     def flatten(self):
         h = C.c_void_p()

@@ -49,6 +49,8 @@ struct _ac_machine {
   struct slab *slabs;
   mtx_t lock;
   void *plan; /* cached device plan, see acm_gpu.hip */
+  struct _ac_state **keywords; /* keyword_id -> terminal state (acm_get_keyword) */
+  size_t keywords_cap;
 };
 
 void (*acm_internal_plan_dropper) (void *plan) = 0;
@@ -261,6 +263,7 @@ acm_release (ACMachine *machine) {
     sl = next;
   }
   mtx_destroy (&machine->lock);
+  free (machine->keywords);
   free (machine);
 }
 
@@ -321,6 +324,12 @@ acm_insert_end_of_keyword (ACState **state, void *value, void (*dtor) (void *)) 
     }
     free (todo.v);
     n->terminal = 1;
+    if (m->nb_keywords == m->keywords_cap) {
+      m->keywords_cap = m->keywords_cap ? 2 * m->keywords_cap : 64;
+      m->keywords = realloc (m->keywords, m->keywords_cap * sizeof *m->keywords);
+      ACM_REQUIRE (m->keywords, "Out of memory.");
+    }
+    m->keywords[m->nb_keywords] = n;
     n->rank = (uint32_t)m->nb_keywords++;
     m->generation++;
   }
@@ -376,6 +385,24 @@ acm_get_match (const ACState *state, size_t index, MatchHolder *matcher) {
   for (const struct _ac_state *s = t; s->parent; s = s->parent)
     matcher->letters[--k] = s->letter;
   matcher->value = t->value;
+}
+
+/* What acm_get_match would have put into the holder for a record of the bulk scan: the
+ * dictionary's letters, the length and the value of keyword `keyword_id` (include/acm_gpu.h). */
+int
+acm_get_keyword (const ACMachine *machine, uint32_t keyword_id, MatchHolder *matcher) {
+  if (!machine || !matcher || keyword_id >= machine->nb_keywords)
+    return ACM_GPU_E_ARG;
+  const struct _ac_state *t = machine->keywords[keyword_id];
+  matcher->length = t->depth;
+  matcher->letters = realloc (matcher->letters, matcher->length * sizeof *matcher->letters);
+  if (!matcher->letters && matcher->length)
+    return ACM_GPU_E_NOMEM;
+  size_t k = matcher->length;
+  for (const struct _ac_state *s = t; s->parent; s = s->parent)
+    matcher->letters[--k] = s->letter;
+  matcher->value = t->value;
+  return ACM_GPU_OK;
 }
 
 size_t

@@ -50,6 +50,12 @@ enum {
 const char *acm_gpu_strerror (int code);
 int acm_gpu_device_count (void);
 
+/* Fills `matcher` (initialised with acm_matcher_init, released with acm_matcher_release) with what
+ * acm_get_match would have produced for a record of the bulk scan: letters[] = the dictionary's
+ * spelling of keyword `keyword_id` (reference aho_corasick.c:472-479), its length and its value
+ * (:480).  Host side, no GPU involved. */
+int acm_get_keyword (const ACMachine *machine, uint32_t keyword_id, MatchHolder *matcher);
+
 /* ------------------------------------------------------------------ flattened tables (host)
  * Snapshot of the machine's goto / failure / output functions as flat arrays (what
  * struct _ac_state holds per node in the reference: transitions :47, fail_state :53,

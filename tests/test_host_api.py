@@ -233,3 +233,27 @@ def test_fatal_error_convention():
     assert "acm_insert_letter_of_keyword should be called first." in err
     assert b"survived" not in p.stdout          # the violating thread was terminated ...
     assert b"main thread alive" in p.stdout     # ... and only that thread (thrd_exit, not exit)
+
+
+def test_get_keyword_rematerialises_match_holder():
+    """acm_get_keyword(id) gives what acm_get_match gives for the same keyword: dictionary letters,
+    length, value; ids are first-insertion ranks (duplicates keep the first rank and value)."""
+    m = acm.Machine(1)
+    vals = [C.c_size_t(100 + i) for i in range(6)]
+    words = [b"bc", b"abc", b"bc", b"c", b"abc", b"zz"]
+    for w, v in zip(words, vals):
+        m.add_keyword(w, C.addressof(v))
+    assert m.nb_keywords == 4
+    distinct = [b"bc", b"abc", b"c", b"zz"]
+    first_val = {b"bc": 100, b"abc": 101, b"c": 103, b"zz": 105}
+    for kid, w in enumerate(distinct):
+        word, value = m.keyword(kid)
+        assert bytes(word) == w
+        assert C.c_size_t.from_address(value).value == first_val[w]
+    with pytest.raises(acm.ACMError):
+        m.keyword(4)
+    # the per-symbol loop reports the same (length, spelling, value) for every match
+    for i, length, word, value in m.match_loop(b"xabczz"):
+        kid = distinct.index(bytes(word))
+        w2, v2 = m.keyword(kid)
+        assert w2 == word and v2 == value and len(w2) == length
