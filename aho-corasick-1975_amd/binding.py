@@ -68,6 +68,7 @@ EXPORTS = [
     "acm_gpu_plan_info", "acm_gpu_scan_device", "acm_gpu_count_device", "acm_gpu_sort_tmp_bytes",
     "acm_gpu_sort_records_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
     "acm_gpu_plan_timing_read", "acm_gpu_plan_status", "acm_gpu_synth_text",
+    "acm_gpu_stream_open", "acm_gpu_stream_feed", "acm_gpu_stream_finish", "acm_gpu_stream_close",
 ]
 
 
@@ -141,6 +142,14 @@ def lib():
     L.acm_gpu_scan_host.argtypes = [vp, vp, u64, u64, u64, vp, u64, C.POINTER(u64)]
     L.acm_scan.restype = i32
     L.acm_scan.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    L.acm_gpu_stream_open.restype = i32
+    L.acm_gpu_stream_open.argtypes = [vp, u64, u64, C.POINTER(vp)]
+    L.acm_gpu_stream_feed.restype = i32
+    L.acm_gpu_stream_feed.argtypes = [vp, vp, u64]
+    L.acm_gpu_stream_finish.restype = i32
+    L.acm_gpu_stream_finish.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.acm_gpu_stream_close.restype = None
+    L.acm_gpu_stream_close.argtypes = [vp]
     L.acm_gpu_plan_status.restype = i32
     L.acm_gpu_plan_status.argtypes = [vp]
     L.acm_gpu_plan_timing.restype = i32
@@ -427,6 +436,9 @@ class Plan:
             _check(rc, "acm_gpu_scan_host")
             return out[:n.value]
 
+    def stream(self, max_piece_symbols, record_capacity):
+        return Stream(self, max_piece_symbols, record_capacity)
+
     def status(self):
         """Synchronises and raises if a device-side consistency check failed."""
         _check(lib().acm_gpu_plan_status(self.h), "acm_gpu_plan_status")
@@ -438,3 +450,42 @@ class Plan:
         ms, n = C.c_double(0), C.c_uint64(0)
         _check(lib().acm_gpu_plan_timing_read(self.h, C.byref(ms), C.byref(n)), "acm_gpu_plan_timing_read")
         return ms.value, int(n.value)
+
+
+class Stream:
+    """acm_gpu_stream_*: feed host buffers piece by piece, get the records of the whole stream."""
+
+    def __init__(self, plan, max_piece_symbols, record_capacity):
+        self.plan = plan
+        self.capacity = int(record_capacity)
+        h = C.c_void_p()
+        _check(lib().acm_gpu_stream_open(plan.h, int(max_piece_symbols), self.capacity, C.byref(h)), "acm_gpu_stream_open")
+        self.h = h
+        self._keep = []
+
+    def feed(self, array):
+        """array: contiguous numpy array (or anything exposing ctypes.data and nbytes) of symbols"""
+        a = np.ascontiguousarray(array)
+        self._keep = (self._keep + [a])[-3:]      # the library reads it asynchronously
+        n = a.size * a.itemsize // self.plan.sym_size
+        _check(lib().acm_gpu_stream_feed(self.h, a.ctypes.data, n), "acm_gpu_stream_feed")
+
+    def feed_ptr(self, ptr, n_symbols):
+        _check(lib().acm_gpu_stream_feed(self.h, ptr, int(n_symbols)), "acm_gpu_stream_feed")
+
+    def finish(self):
+        out = np.zeros(self.capacity, dtype=RECORD_DTYPE)
+        n = C.c_uint64(0)
+        _check(lib().acm_gpu_stream_finish(self.h, out.ctypes.data, self.capacity, C.byref(n)), "acm_gpu_stream_finish")
+        return out[:n.value]
+
+    def close(self):
+        if self.h:
+            lib().acm_gpu_stream_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1053,6 +1053,12 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     delete p;
     return ACM_GPU_E_HIP;
   }
+  if (hipMalloc (reinterpret_cast<void **> (&p->d_total), 16) != hipSuccess ||
+      hipMemset (p->d_total, 0, 16) != hipSuccess) {
+    (void)hipFree (p->blob);
+    delete p;
+    return ACM_GPU_E_NOMEM;
+  }
   unsigned char *b = static_cast<unsigned char *> (p->blob);
   auto u32p = [&] (size_t off) { return reinterpret_cast<const uint32_t *> (b + off); };
   p->csr.row_ptr = u32p (o_row);
@@ -1265,11 +1271,6 @@ ensure_item_buffer (ACMPlan *p, uint64_t n) {
   if (hipMalloc (reinterpret_cast<void **> (&p->d_fill), (size_t)regions * 4) != hipSuccess)
     return ACM_GPU_E_NOMEM;
   HIP_TRY (hipMemset (p->d_fill, 0, (size_t)regions * 4));
-  if (!p->d_total) {
-    if (hipMalloc (reinterpret_cast<void **> (&p->d_total), 16) != hipSuccess)
-      return ACM_GPU_E_NOMEM;
-    HIP_TRY (hipMemset (p->d_total, 0, 16));
-  }
   p->regions = regions;
   p->region_items = (uint32_t)per;
   return ACM_GPU_OK;
@@ -1325,11 +1326,13 @@ launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
 template <bool COUNT_ONLY>
 int
 scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint64_t pos_base, ACMRecord *d_records,
-           uint64_t capacity, uint64_t *d_count, hipStream_t st) {
+           uint64_t capacity, uint64_t *d_count, hipStream_t st, bool accumulate = false) {
+  /* accumulate (streaming): records are appended after those of earlier calls -- the plan's
+   * running total keeps counting and is handed over by acm_gpu_stream_finish, not here */
   HIP_TRY (hipSetDevice (p->device));
   const uint32_t sb = p->finfo.sym_bytes;
   const bool use_dense = p->info.kernel == 1 && (reinterpret_cast<uintptr_t> (d_text) & 15) == 0;
-  if (n == 0 || p->finfo.n_edges == 0 || emit_from >= n || !use_dense)
+  if (!accumulate && (n == 0 || p->finfo.n_edges == 0 || emit_from >= n || !use_dense))
     HIP_TRY (hipMemsetAsync (d_count, 0, sizeof (uint64_t), st));
   if (n == 0 || p->finfo.n_edges == 0 || emit_from >= n)
     return ACM_GPU_OK;
@@ -1341,7 +1344,7 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   EmitCtx E{};
   E.oinfo = p->d_oinfo;
   E.records = d_records;
-  E.count = use_dense ? p->d_total : reinterpret_cast<unsigned long long *> (d_count);
+  E.count = (use_dense || accumulate) ? p->d_total : reinterpret_cast<unsigned long long *> (d_count);
   E.capacity = COUNT_ONLY ? 0 : capacity;
   E.wrows = p->d_wrows;
   E.cont_dh = p->d_cont_dh;
@@ -1374,7 +1377,7 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     if (rc)
       return rc;
     if (use_dense)
-      rc = launch_dense<COUNT_ONLY> (p, E, a, st, stop, d_count, seg_end == n);
+      rc = launch_dense<COUNT_ONLY> (p, E, a, st, stop, d_count, seg_end == n && !accumulate);
     else {
       a.range_begin = 0;
       a.range_end = a.n;
@@ -1405,6 +1408,161 @@ acm_gpu_count_device (ACMPlan *plan, const void *d_text, uint64_t n_symbols, uin
   if (!plan || !d_count || (n_symbols && !d_text))
     return ACM_GPU_E_ARG;
   return scan_impl<true> (plan, d_text, n_symbols, emit_from, 0, nullptr, 0, d_count, static_cast<hipStream_t> (stream));
+}
+
+/* ------------------------------------------------------------------ streaming scan
+ * The reference's callers read their text piece by piece (generic_test.c:191 uses fgetwc) and the
+ * scan is resumable by construction: the cursor depends on the last lmax symbols only.  A stream
+ * keeps two device slots; piece k is copied into slot k % 2 on a copy stream while piece k - 1 is
+ * scanned on the compute stream; the last `halo` symbols of the stream so far are placed in front
+ * of every piece so that matches straddling pieces are found (reported once: emit_from = halo). */
+struct ACMStream {
+  ACMPlan *plan = nullptr;
+  uint32_t sb = 1;
+  uint64_t halo = 0, max_piece = 0;
+  unsigned char *slot[2] = { nullptr, nullptr }; /* (halo + max_piece) symbols each */
+  hipStream_t copy = nullptr, compute = nullptr;
+  hipEvent_t copied[2] = { nullptr, nullptr }, scanned[2] = { nullptr, nullptr }, tail_read[2] = { nullptr, nullptr };
+  ACMRecord *d_records = nullptr;
+  uint64_t capacity = 0;
+  uint64_t position = 0; /* symbols fed so far */
+  uint64_t pieces = 0;
+  uint64_t prev_valid = 0; /* context + piece symbols held, contiguously, by the previous slot */
+  uint64_t last_piece = 0; /* length of the previous piece */
+  uint64_t prev_piece_len () const { return last_piece; }
+};
+
+extern "C" int
+acm_gpu_stream_open (ACMPlan *plan, uint64_t max_piece_symbols, uint64_t record_capacity, ACMStream **out) {
+  if (!plan || !out || max_piece_symbols == 0)
+    return ACM_GPU_E_ARG;
+  HIP_TRY (hipSetDevice (plan->device));
+  ACMStream *s = new (std::nothrow) ACMStream ();
+  if (!s)
+    return ACM_GPU_E_NOMEM;
+  s->plan = plan;
+  s->sb = plan->finfo.sym_bytes;
+  s->halo = plan->finfo.lmax > 1 ? (((uint64_t)plan->finfo.lmax - 1 + 15) / 16) * 16 : 0;
+  s->max_piece = (max_piece_symbols + 15) / 16 * 16;
+  s->capacity = record_capacity;
+  const size_t slot_bytes = (size_t)(s->halo + s->max_piece) * s->sb + 16;
+  bool ok = hipMalloc (reinterpret_cast<void **> (&s->slot[0]), slot_bytes) == hipSuccess &&
+            hipMalloc (reinterpret_cast<void **> (&s->slot[1]), slot_bytes) == hipSuccess &&
+            hipMalloc (reinterpret_cast<void **> (&s->d_records), (record_capacity ? record_capacity : 1) * sizeof (ACMRecord)) == hipSuccess &&
+            hipStreamCreateWithFlags (&s->copy, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags (&s->compute, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < 2; i++)
+    ok = hipEventCreateWithFlags (&s->copied[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags (&s->scanned[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags (&s->tail_read[i], hipEventDisableTiming) == hipSuccess;
+  /* a stream owns the plan's running total while it is open: start from zero */
+  ok = ok && hipMemset (plan->d_total, 0, 8) == hipSuccess;
+  if (!ok) {
+    acm_gpu_stream_close (s);
+    return ACM_GPU_E_NOMEM;
+  }
+  *out = s;
+  return ACM_GPU_OK;
+}
+
+/* Feeds the next n_symbols of the stream from HOST memory (pinned memory makes the copy truly
+ * asynchronous).  Returns as soon as the copy and the scan are enqueued; `text` must stay
+ * untouched until the next feed of the same parity, acm_gpu_stream_finish or _sync. */
+extern "C" int
+acm_gpu_stream_feed (ACMStream *s, const void *text, uint64_t n_symbols) {
+  if (!s || (n_symbols && !text))
+    return ACM_GPU_E_ARG;
+  ACMPlan *p = s->plan;
+  HIP_TRY (hipSetDevice (p->device));
+  const unsigned char *src = static_cast<const unsigned char *> (text);
+  while (n_symbols) {
+    const uint64_t n = n_symbols < s->max_piece ? n_symbols : s->max_piece;
+    const int cur = (int)(s->pieces & 1), prev = cur ^ 1;
+    unsigned char *piece_at = s->slot[cur] + s->halo * s->sb;
+    /* the slot is free once the scan that used it two pieces ago is done and the previous piece
+     * has taken its context from the slot's tail */
+    if (s->pieces >= 2)
+      HIP_TRY (hipStreamWaitEvent (s->copy, s->scanned[cur], 0));
+    if (s->pieces >= 1)
+      HIP_TRY (hipStreamWaitEvent (s->copy, s->tail_read[cur], 0));
+    HIP_TRY (hipMemcpyAsync (piece_at, src, (size_t)n * s->sb, hipMemcpyHostToDevice, s->copy));
+    HIP_TRY (hipEventRecord (s->copied[cur], s->copy));
+    /* context: the last `ctx` symbols the previous slot holds, end-aligned in front of the piece */
+    const uint64_t ctx = s->prev_valid < s->halo ? s->prev_valid : s->halo;
+    HIP_TRY (hipStreamWaitEvent (s->compute, s->copied[cur], 0));
+    if (ctx) {
+      const unsigned char *tail = s->slot[prev] + (s->halo + s->prev_piece_len () - ctx) * s->sb;
+      HIP_TRY (hipMemcpyAsync (piece_at - ctx * s->sb, tail, (size_t)ctx * s->sb, hipMemcpyDeviceToDevice, s->compute));
+    }
+    HIP_TRY (hipEventRecord (s->tail_read[prev], s->compute));
+    int rc = scan_impl<false> (p, piece_at - ctx * s->sb, ctx + n, ctx, s->position - ctx, s->d_records, s->capacity, nullptr,
+                               s->compute, true);
+    if (rc)
+      return rc;
+    HIP_TRY (hipEventRecord (s->scanned[cur], s->compute));
+    s->prev_valid = ctx + n;
+    s->last_piece = n;
+    s->position += n;
+    s->pieces++;
+    src += (size_t)n * s->sb;
+    n_symbols -= n;
+  }
+  return ACM_GPU_OK;
+}
+
+/* Waits for everything fed so far, puts the records in canonical order and copies them to the
+ * host.  *n_found = matches of the whole stream so far (ACM_GPU_E_OVERFLOW if more than the
+ * stream's record capacity or than `capacity`).  The stream stays open and keeps accumulating. */
+extern "C" int
+acm_gpu_stream_finish (ACMStream *s, ACMRecord *records, uint64_t capacity, uint64_t *n_found) {
+  if (!s || !n_found)
+    return ACM_GPU_E_ARG;
+  ACMPlan *p = s->plan;
+  HIP_TRY (hipSetDevice (p->device));
+  HIP_TRY (hipStreamSynchronize (s->copy));
+  HIP_TRY (hipStreamSynchronize (s->compute));
+  unsigned long long total = 0;
+  HIP_TRY (hipMemcpy (&total, p->d_total, 8, hipMemcpyDeviceToHost));
+  *n_found = total;
+  if (total > s->capacity || total > capacity)
+    return ACM_GPU_E_OVERFLOW;
+  if (total > 1) {
+    const size_t tb = acm_gpu_sort_tmp_bytes (total);
+    void *tmp = nullptr;
+    if (hipMalloc (&tmp, tb) != hipSuccess)
+      return ACM_GPU_E_NOMEM;
+    int rc = acm_gpu_sort_records_device (p, s->d_records, total, tmp, tb, s->compute);
+    if (!rc && hipStreamSynchronize (s->compute) != hipSuccess)
+      rc = ACM_GPU_E_HIP;
+    (void)hipFree (tmp);
+    if (rc)
+      return rc;
+  }
+  if (total && records)
+    HIP_TRY (hipMemcpy (records, s->d_records, total * sizeof (ACMRecord), hipMemcpyDeviceToHost));
+  return acm_gpu_plan_status (p);
+}
+
+extern "C" void
+acm_gpu_stream_close (ACMStream *s) {
+  if (!s)
+    return;
+  (void)hipSetDevice (s->plan->device);
+  if (s->copy)
+    (void)hipStreamSynchronize (s->copy);
+  if (s->compute)
+    (void)hipStreamSynchronize (s->compute);
+  (void)hipMemset (s->plan->d_total, 0, 8); /* hand the plan back with a clean running total */
+  for (int i = 0; i < 2; i++) {
+    if (s->slot[i]) (void)hipFree (s->slot[i]);
+    if (s->copied[i]) (void)hipEventDestroy (s->copied[i]);
+    if (s->scanned[i]) (void)hipEventDestroy (s->scanned[i]);
+    if (s->tail_read[i]) (void)hipEventDestroy (s->tail_read[i]);
+  }
+  if (s->d_records) (void)hipFree (s->d_records);
+  if (s->copy) (void)hipStreamDestroy (s->copy);
+  if (s->compute) (void)hipStreamDestroy (s->compute);
+  delete s;
 }
 
 /* ------------------------------------------------------------------ canonical order */

@@ -158,6 +158,25 @@ int acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint
 int acm_scan (ACMachine *machine, const void *text, uint64_t n_symbols, ACMRecord *records,
               uint64_t capacity, uint64_t *n_found);
 
+/* ------------------------------------------------------------------ streaming scan
+ * Text that arrives piece by piece from the host (the reference's callers read files symbol by
+ * symbol, generic_test.c:191).  The result is the caller loop's output over the concatenation of
+ * all pieces fed so far (end_pos = position in the whole stream): the last lmax - 1 symbols are
+ * carried over in front of every piece.  Host-to-device copies of a piece overlap with the scan of
+ * the previous one (two device slots, two streams).  One open stream per plan at a time; do not
+ * mix with acm_gpu_scan_* calls on the same plan while it is open. */
+typedef struct ACMStream ACMStream;
+int acm_gpu_stream_open (ACMPlan *plan, uint64_t max_piece_symbols, uint64_t record_capacity, ACMStream **out);
+/* Enqueues copy + scan of the next n_symbols (split into pieces of at most max_piece_symbols) and
+ * returns; `text` (host memory, pinned for a truly asynchronous copy) must stay untouched until
+ * the second next feed or acm_gpu_stream_finish. */
+int acm_gpu_stream_feed (ACMStream *stream, const void *text, uint64_t n_symbols);
+/* Waits, sorts into canonical order, copies the records of the whole stream so far to the host.
+ * ACM_GPU_E_OVERFLOW (with *n_found = number needed) if they exceed the stream's or this call's
+ * capacity.  The stream stays open. */
+int acm_gpu_stream_finish (ACMStream *stream, ACMRecord *records, uint64_t capacity, uint64_t *n_found);
+void acm_gpu_stream_close (ACMStream *stream);
+
 /* Waits for the plan's device and reports ACM_GPU_E_INTERNAL if a device-side consistency check
  * ever failed during its scans (never expected), else ACM_GPU_OK. */
 int acm_gpu_plan_status (ACMPlan *plan);

@@ -306,3 +306,43 @@ def test_config5_full_size_properties(torch_cuda):
     assert found >= (n // 4096)         # at least the planted keywords
     del text
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("piece", [7, 100, 4096, 50000])
+def test_streaming_pieces_equal_whole_scan(torch_cuda, novel_bytes, piece):
+    """acm_gpu_stream_*: the novel fed in ragged pieces (shorter than a keyword, shorter than the
+    halo, around a tile) gives the records of the whole scan; config 1 dictionary."""
+    m, o = build_pair([b"he", b"she", b"his", b"hers"], 1)
+    text = np.frombuffer(novel_bytes, np.uint8)[:120000 if piece < 1000 else None]
+    want = o.scan(text)
+    plan = m.plan(0)
+    st = plan.stream(max_piece_symbols=max(piece, 16), record_capacity=want.size + 10)
+    rng = np.random.default_rng(piece)
+    i = 0
+    while i < text.size:
+        n = int(rng.integers(1, piece + 1))
+        st.feed(text[i:i + n].copy())
+        i += n
+    got = st.finish()
+    assert np.array_equal(got, want)
+    st.close()
+    # the plan is usable for plain scans again
+    assert np.array_equal(plan.scan_sorted(_dev(torch_cuda, text)), want)
+
+
+def test_streaming_synthetic_large_pieces(torch_cuda):
+    """1k-keyword dictionary, 64 MiB fed in 8 MiB pieces from pinned host memory; digest of
+    SURVEY.md App. C; then more pieces keep accumulating."""
+    torch = torch_cuda
+    kd, ko = acm.synth.keywords(1000)
+    m = acm.Machine(1)
+    m.add_keywords_packed(kd, ko)
+    plan = m.plan(0)
+    n = 1 << 26
+    host = acm.synth.device_text(n, kd, ko).cpu().pin_memory()
+    st = plan.stream(max_piece_symbols=8 << 20, record_capacity=1 << 17)
+    st.feed_ptr(host.data_ptr(), n)
+    got = st.finish()
+    assert got.size == 35453 and po.digest(got) == 0x75c631ca92f2fd08
+    assert np.all(np.diff(got["end_pos"].astype(np.int64)) >= 0)
+    st.close()
