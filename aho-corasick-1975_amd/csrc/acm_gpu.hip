@@ -101,7 +101,12 @@ struct Launch {
   uint32_t n;                /* symbols in the segment */
   uint32_t emit_from;        /* matches ending before this index are not reported */
   uint32_t range_begin, range_end; /* dense: tile indices; csr: symbol indices */
+  /* dense: tiles [range_begin, static_end) are split evenly between the blocks; [static_end,
+   * range_end) is a pool in POOL_CLASSES equal parts, handed out tile by tile through pool_ctr */
+  uint32_t static_end, pool_class_tiles;
+  unsigned int *pool_ctr, *pool_reset; /* this launch's counters; the previous launch's, to zero */
 };
+static constexpr uint32_t POOL_CLASSES = 16, POOL_CTR_STRIDE = 64; /* counters 256 B apart */
 
 /* small uniform constants of the dense kernel */
 struct DenseK {
@@ -585,6 +590,11 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
     for (uint32_t i = threadIdx.x; i < lds_image_bytes / 16; i += blockDim.x)
       dst[i] = lds_image[i];
   }
+  /* tiles are handed out dynamically inside the workgroup (its waves do not run at the same
+   * pace: a static split left the slowest wave of a block 11% behind the block's mean) */
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + (DENSE_THREADS / WAVE) * QCAP * 8);
+  if (threadIdx.x == 0)
+    *next_tile = 0;
   __syncthreads ();
 
   const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -592,9 +602,41 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
   uint2 *queue = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
   const uint32_t waves_per_block = blockDim.x / WAVE;
   const uint32_t wave = blockIdx.x * waves_per_block + wib;
-  const uint32_t nwaves = gridDim.x * waves_per_block;
   const uint32_t emit_from = A.emit_from, emit_end = A.n;
   const uint32_t last_block = (A.n - 1) & ~15u; /* byte offset of the last 16-byte block with a valid byte */
+  /* Work split.  Block b owns the contiguous tiles [blk_begin, blk_begin + blk_tiles), handed to
+   * its waves through an LDS counter; once those are gone its waves draw single tiles from the
+   * pool of their class (16 consecutive blocks = 2 per XCD; one counter per class keeps the
+   * atomics per counter far below what one address sustains).  Blocks ran up to 6% apart. */
+  const uint32_t tiles_per_block = (A.static_end - A.range_begin + gridDim.x - 1) / gridDim.x;
+  const uint32_t blk_begin = A.range_begin + blockIdx.x * tiles_per_block;
+  const uint32_t blk_tiles = blk_begin >= A.static_end ? 0
+                             : (A.static_end - blk_begin < tiles_per_block ? A.static_end - blk_begin : tiles_per_block);
+  const uint32_t cls = blockIdx.x * POOL_CLASSES / gridDim.x;
+  const uint32_t cls_begin = A.static_end + cls * A.pool_class_tiles;
+  const uint32_t cls_tiles = cls_begin >= A.range_end ? 0
+                             : (A.range_end - cls_begin < A.pool_class_tiles ? A.range_end - cls_begin : A.pool_class_tiles);
+  unsigned int *const cls_ctr = A.pool_ctr + cls * POOL_CTR_STRIDE;
+  if (blockIdx.x == 0 && threadIdx.x < POOL_CLASSES)
+    A.pool_reset[threadIdx.x * POOL_CTR_STRIDE] = 0;
+  /* next tile of this wave, valid in lane 0 (A.range_end = none left); made uniform only where
+   * it is used, one tile later, so that the atomics' latency stays hidden */
+  auto grab_tile = [&] () -> uint32_t {
+    uint32_t t = A.range_end;
+    if (lane == 0) {
+      const uint32_t i = atomicAdd (next_tile, 1u);
+      if (i < blk_tiles)
+        t = blk_begin + i;
+      else if (cls_tiles) {
+        const uint32_t g = atomicAdd (cls_ctr, 1u);
+        if (g < cls_tiles)
+          t = cls_begin + g;
+      }
+    }
+    return t;
+  };
+  uint32_t cur = uniform (grab_tile ());
+  uint32_t nxt_raw = cur < A.range_end ? grab_tile () : A.range_end;
 
   Walk<S> w;
   w.qn = 0;
@@ -602,7 +644,7 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
   w.spill.region = items + (size_t)wave * region_items;
   w.spill.capacity = items ? region_items : 0;
   w.spill.fill = 0;
-  DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_text = 0, d_tiles = 0;)
+  DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); const unsigned long long d_w0 = wall_clock64 (); unsigned long long d_text = 0, d_tiles = 0;)
 
   static_assert (NB == 4, "the software pipeline below is written out for 4 blocks per chunk");
   uint4 d[NB][S], post[S];
@@ -611,7 +653,7 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
     return *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
   };
   {
-    const uint32_t p0 = (A.range_begin + wave) * TILE + lane * C;
+    const uint32_t p0 = cur * TILE + lane * C;
 #pragma unroll
     for (int q = 0; q < S; q++) {
       d[0][q] = load_block (p0, 0, q);
@@ -622,10 +664,13 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
     }
   }
 
-  for (uint32_t tile = A.range_begin + wave; tile < A.range_end; tile += nwaves) {
-    const uint32_t tbase = tile * TILE;
-    const uint32_t pos0 = tbase + lane * C;        /* first byte of this lane's stream 0 */
-    const uint32_t npos0 = pos0 + nwaves * TILE;   /* the same lane's place in the wave's next tile */
+  while (cur < A.range_end) {
+    const uint32_t nxt = uniform (nxt_raw);
+    const uint32_t pos0 = cur * TILE + lane * C;  /* first byte of this lane's stream 0 */
+    const uint32_t npos0 = nxt * TILE + lane * C; /* the same lane's place in the wave's next tile */
+    cur = nxt;
+    if (nxt < A.range_end)
+      nxt_raw = grab_tile ();
     DIAG (const unsigned long long d_tl = __builtin_readcyclecounter ();)
 #pragma unroll
     for (int q = 0; q < S; q++)
@@ -717,7 +762,8 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
   DIAG (if (lane == 0 && wave < 8192) {
     unsigned long long *o = g_acm_diag[wave];
     o[0] = __builtin_readcyclecounter () - d_t0;
-    o[1] = 0;
+    o[1] = wall_clock64 ();
+    o[7] = d_w0;
     o[2] = w.spill.fill;
     o[3] = w.d_slow_steps;
     o[4] = w.d_slow_cycles;
@@ -856,6 +902,8 @@ struct ACMPlan {
   void *d_items = nullptr;
   uint32_t *d_fill = nullptr;   /* per region, zero between launches */
   unsigned long long *d_total = nullptr; /* [0] running total of a scan, [1] low word = expand ticket; zero between scans */
+  unsigned int *d_pool_ctr = nullptr;    /* 2 x POOL_CLASSES tile-pool counters (same allocation), alternating per launch */
+  uint32_t launch_seq = 0;
   uint32_t regions = 0, region_items = 0;
   uint64_t segment = SEGMENT;
   uint64_t generation = 0; /* for the machine-cached plan */
@@ -1053,12 +1101,14 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     delete p;
     return ACM_GPU_E_HIP;
   }
-  if (hipMalloc (reinterpret_cast<void **> (&p->d_total), 16) != hipSuccess ||
-      hipMemset (p->d_total, 0, 16) != hipSuccess) {
+  const size_t ctl_bytes = 16 + 2 * POOL_CLASSES * POOL_CTR_STRIDE * sizeof (unsigned int);
+  if (hipMalloc (reinterpret_cast<void **> (&p->d_total), ctl_bytes) != hipSuccess ||
+      hipMemset (p->d_total, 0, ctl_bytes) != hipSuccess) {
     (void)hipFree (p->blob);
     delete p;
     return ACM_GPU_E_NOMEM;
   }
+  p->d_pool_ctr = reinterpret_cast<unsigned int *> (p->d_total + 2);
   unsigned char *b = static_cast<unsigned char *> (p->blob);
   auto u32p = [&] (size_t off) { return reinterpret_cast<const uint32_t *> (b + off); };
   p->csr.row_ptr = u32p (o_row);
@@ -1097,7 +1147,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   I.dense_rows = dense ? n : 0;
   I.lds_rows = HD;
   I.lds_hotfail = cont ? n - HD : 0;
-  I.lds_bytes = dense ? image_bytes + queue_bytes : QCAP * 8;
+  I.lds_bytes = dense ? image_bytes + queue_bytes + 16 /* tile counter */ : QCAP * 8;
   I.block_threads = dense ? DENSE_THREADS : WAVE;
   I.grid_blocks = dense ? (uint32_t)p->cu_count : (uint32_t)p->cu_count * 16;
   I.chunk_bytes = p->chunk;
@@ -1305,6 +1355,13 @@ launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
   const uint32_t blocks_needed = (a.range_end + wpb - 1) / wpb;
   if (blocks_needed < grid)
     grid = blocks_needed;
+  /* the last 1/16 of the tiles is the dynamic pool (none for inputs of a few tiles per wave) */
+  const uint32_t pool = a.range_end >= grid * wpb * 8 ? a.range_end / 16 : 0;
+  a.static_end = a.range_end - pool;
+  a.pool_class_tiles = (pool + POOL_CLASSES - 1) / POOL_CLASSES;
+  a.pool_ctr = p->d_pool_ctr + (p->launch_seq & 1) * POOL_CLASSES * POOL_CTR_STRIDE;
+  a.pool_reset = p->d_pool_ctr + ((p->launch_seq & 1) ^ 1) * POOL_CLASSES * POOL_CTR_STRIDE;
+  p->launch_seq++;
   void *args[] = { &p->K, const_cast<EmitCtx *> (&E), &a, &p->d_dense, &p->d_lds_image, &p->lds_image_bytes, &a.text,
                    &p->d_items, &p->region_items, &p->d_fill, &p->d_dstart };
   HIP_TRY (hipLaunchKernel (dense_kernel_ptr (p->entry_bytes, p->chunk, p->streams, COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), args,
