@@ -64,7 +64,8 @@ EXPORTS = [
     "acm_insert_letter_of_keyword", "acm_insert_end_of_keyword", "acm_match", "acm_matcher_init", "acm_get_match",
     "acm_matcher_release", "acm_nb_keywords", "acm_foreach_keyword", "acm_release", "acm_print",
     "acm_gpu_strerror", "acm_gpu_device_count", "acm_get_keyword", "acm_flatten", "acm_flat_release", "acm_flat_info", "acm_flat_view",
-    "acm_flat_dense_rows", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_destroy",
+    "acm_flat_dense_rows", "acm_flat_blob_bytes", "acm_flat_to_blob", "acm_flat_from_blob", "acm_flat_save",
+    "acm_flat_load", "acm_flat_keyword", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_destroy",
     "acm_gpu_plan_info", "acm_gpu_scan_device", "acm_gpu_count_device", "acm_gpu_sort_tmp_bytes",
     "acm_gpu_sort_records_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
     "acm_gpu_plan_timing_read", "acm_gpu_plan_status", "acm_gpu_synth_text",
@@ -122,6 +123,18 @@ def lib():
     L.acm_flat_view.argtypes = [vp, C.POINTER(FlatView)]
     L.acm_flat_dense_rows.restype = i32
     L.acm_flat_dense_rows.argtypes = [vp, u32, u32, vp]
+    L.acm_flat_blob_bytes.restype = sz
+    L.acm_flat_blob_bytes.argtypes = [vp]
+    L.acm_flat_to_blob.restype = i32
+    L.acm_flat_to_blob.argtypes = [vp, vp, sz]
+    L.acm_flat_from_blob.restype = i32
+    L.acm_flat_from_blob.argtypes = [vp, sz, C.POINTER(vp)]
+    L.acm_flat_save.restype = i32
+    L.acm_flat_save.argtypes = [vp, C.c_char_p]
+    L.acm_flat_load.restype = i32
+    L.acm_flat_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.acm_flat_keyword.restype = i32
+    L.acm_flat_keyword.argtypes = [vp, u32, vp, u32, C.POINTER(u32)]
     L.acm_gpu_plan_create.restype = i32
     L.acm_gpu_plan_create.argtypes = [vp, i32, C.POINTER(vp)]
     L.acm_gpu_plan_create_flat.restype = i32
@@ -203,6 +216,46 @@ class FlatTables:
         out = np.zeros(n_rows * info.width, dtype=np.uint16 if entry_bytes == 2 else np.uint32)
         _check(lib().acm_flat_dense_rows(self._h, n_rows, entry_bytes, out.ctypes.data), "acm_flat_dense_rows")
         return out.reshape(n_rows, info.width)
+
+    # ---- serialised form (acm_flat_to_blob / acm_flat_from_blob / acm_flat_save / acm_flat_load)
+    def to_bytes(self):
+        L = lib()
+        n = L.acm_flat_blob_bytes(self._h)
+        buf = (C.c_ubyte * n)()
+        _check(L.acm_flat_to_blob(self._h, buf, n), "acm_flat_to_blob")
+        return bytes(buf)
+
+    @classmethod
+    def from_bytes(cls, blob):
+        h = C.c_void_p()
+        buf = (C.c_ubyte * max(len(blob), 1)).from_buffer_copy(blob if len(blob) else b"\0")
+        _check(lib().acm_flat_from_blob(buf, len(blob), C.byref(h)), "acm_flat_from_blob")
+        return cls(h)
+
+    def save(self, path):
+        _check(lib().acm_flat_save(self._h, os.fsencode(path)), "acm_flat_save")
+
+    @classmethod
+    def load(cls, path):
+        h = C.c_void_p()
+        _check(lib().acm_flat_load(os.fsencode(path), C.byref(h)), "acm_flat_load")
+        return cls(h)
+
+    def keyword(self, keyword_id):
+        """Spelling of a keyword from the tables alone: numpy array of symbols."""
+        sb = self.info.sym_bytes
+        n = C.c_uint32(0)
+        L = lib()
+        _check(L.acm_flat_keyword(self._h, keyword_id, None, 0, C.byref(n)), "acm_flat_keyword")
+        out = np.zeros(n.value, dtype={1: np.uint8, 2: np.uint16, 4: np.uint32}[sb])
+        _check(L.acm_flat_keyword(self._h, keyword_id, out.ctypes.data, n.value, C.byref(n)), "acm_flat_keyword")
+        return out
+
+    def plan(self, device=0):
+        """Device plan straight from the tables (no machine needed: acm_gpu_plan_create_flat)."""
+        h = C.c_void_p()
+        _check(lib().acm_gpu_plan_create_flat(self._h, device, C.byref(h)), "acm_gpu_plan_create_flat")
+        return Plan(h, self.info.sym_bytes)
 
     def close(self):
         if self._h:

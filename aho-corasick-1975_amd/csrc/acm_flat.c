@@ -9,6 +9,7 @@
 #define _GNU_SOURCE
 #include "acm_internal.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -249,5 +250,316 @@ acm_flat_dense_rows (const ACMFlat *f, uint32_t n_rows, uint32_t entry_bytes, vo
       ((uint32_t *)out)[i] = ent;
   }
   free (rows);
+  return ACM_GPU_OK;
+}
+
+/* ------------------------------------------------------------------ serialised form
+ * The reference has no on-disk form of a built machine (it is rebuilt from its keywords at each
+ * start).  A blob is the flat tables verbatim:
+ *
+ *   header, 80 bytes: "AC75FLAT" | u32 version (1) | u32 0x01020304 (byte-order probe) |
+ *                     ACMFlatInfo (9 x u32) | u32 0 | u64 payload bytes | u64 FNV-1a-64 of payload |
+ *                     u64 0
+ *   payload, u32 arrays in this order: row_ptr[n+1] edge_sym[E] edge_next[E] fail[n] depth[n]
+ *                     nb_outputs[n] term_kw[n] out_link[n] depth_start[lmax+2] kw_state[K]
+ *
+ * Loading trusts nothing: the goto function (row_ptr, edge_sym, term_kw) is checked for shape,
+ * every other array -- the failure function included -- is recomputed from it and compared.  A
+ * blob that loads therefore holds exactly what acm_flatten would have produced, and cannot send a
+ * device walker out of its tables. */
+#define BLOB_MAGIC "AC75FLAT"
+#define BLOB_VERSION 1u
+#define BLOB_HEADER 80u
+
+static uint64_t
+fnv1a64 (const unsigned char *p, size_t n) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (size_t i = 0; i < n; i++)
+    h = (h ^ p[i]) * 0x100000001b3ull;
+  return h;
+}
+
+static size_t
+blob_payload_words (const ACMFlatInfo *in) {
+  const size_t n = in->n_states, e = in->n_edges;
+  return (n + 1) + 2 * e + 5 * n + ((size_t)in->lmax + 2) + in->n_keywords;
+}
+
+size_t
+acm_flat_blob_bytes (const ACMFlat *f) {
+  return f ? BLOB_HEADER + 4 * blob_payload_words (&f->info) : 0;
+}
+
+int
+acm_flat_to_blob (const ACMFlat *f, void *out, size_t capacity) {
+  if (!f || !out || capacity < acm_flat_blob_bytes (f))
+    return ACM_GPU_E_ARG;
+  const ACMFlatInfo *in = &f->info;
+  unsigned char *b = out, *p = b + BLOB_HEADER;
+#define PUT(arr, cnt)                                                                              \
+  do {                                                                                             \
+    memcpy (p, (arr), (size_t)(cnt) * 4);                                                          \
+    p += (size_t)(cnt) * 4;                                                                        \
+  } while (0)
+  PUT (f->row_ptr, (size_t)in->n_states + 1);
+  PUT (f->edge_sym, in->n_edges);
+  PUT (f->edge_next, in->n_edges);
+  PUT (f->fail, in->n_states);
+  PUT (f->depth, in->n_states);
+  PUT (f->nb_outputs, in->n_states);
+  PUT (f->term_kw, in->n_states);
+  PUT (f->out_link, in->n_states);
+  PUT (f->depth_start, (size_t)in->lmax + 2);
+  PUT (f->kw_state, in->n_keywords);
+#undef PUT
+  const uint64_t payload = (uint64_t)(p - (b + BLOB_HEADER));
+  const uint64_t sum = fnv1a64 (b + BLOB_HEADER, (size_t)payload);
+  const uint32_t version = BLOB_VERSION, probe = 0x01020304u, zero = 0;
+  const uint64_t zero64 = 0;
+  memcpy (b, BLOB_MAGIC, 8);
+  memcpy (b + 8, &version, 4);
+  memcpy (b + 12, &probe, 4);
+  memcpy (b + 16, in, sizeof *in); /* 36 bytes */
+  memcpy (b + 52, &zero, 4);
+  memcpy (b + 56, &payload, 8);
+  memcpy (b + 64, &sum, 8);
+  memcpy (b + 72, &zero64, 8);
+  return ACM_GPU_OK;
+}
+
+/* goto edge of state s on symbol c in a CSR with rows in ascending symbol order; UINT32_MAX if none */
+static uint32_t
+csr_child (const uint32_t *row_ptr, const uint32_t *edge_sym, uint32_t s, uint32_t c) {
+  uint32_t lo = row_ptr[s], hi = row_ptr[s + 1];
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (edge_sym[mid] < c)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo < row_ptr[s + 1] && edge_sym[lo] == c ? lo + 1 : UINT32_MAX; /* edge e leads to state e + 1 */
+}
+
+int
+acm_flat_from_blob (const void *blob, size_t bytes, ACMFlat **out) {
+  if (!blob || !out)
+    return ACM_GPU_E_ARG;
+  *out = NULL;
+  const unsigned char *b = blob;
+  uint32_t version, probe;
+  uint64_t payload, sum;
+  ACMFlatInfo in;
+  if (bytes < BLOB_HEADER || memcmp (b, BLOB_MAGIC, 8) != 0)
+    return ACM_GPU_E_FORMAT;
+  memcpy (&version, b + 8, 4);
+  memcpy (&probe, b + 12, 4);
+  memcpy (&in, b + 16, sizeof in);
+  memcpy (&payload, b + 56, 8);
+  memcpy (&sum, b + 64, 8);
+  if (version != BLOB_VERSION || probe != 0x01020304u)
+    return ACM_GPU_E_FORMAT;
+  if (in.n_states == 0 || in.n_edges != in.n_states - 1 || in.n_keywords > in.n_states ||
+      in.lmax >= in.n_states + 1 || (in.sym_bytes != 1 && in.sym_bytes != 2 && in.sym_bytes != 4))
+    return ACM_GPU_E_FORMAT;
+  if (payload != 4ull * blob_payload_words (&in) || bytes - BLOB_HEADER < payload ||
+      fnv1a64 (b + BLOB_HEADER, (size_t)payload) != sum)
+    return ACM_GPU_E_FORMAT;
+
+  const uint32_t n = in.n_states, E = in.n_edges;
+  ACMFlat *f = calloc (1, sizeof *f);
+  if (!f)
+    return ACM_GPU_E_NOMEM;
+  const unsigned char *p = b + BLOB_HEADER;
+  int bad = 0;
+#define GET(field, cnt)                                                                            \
+  do {                                                                                             \
+    const size_t c_ = (size_t)(cnt);                                                               \
+    f->field = malloc ((c_ ? c_ : 1) * 4);                                                         \
+    if (!f->field)                                                                                 \
+      bad = 1;                                                                                     \
+    else                                                                                           \
+      memcpy (f->field, p, c_ * 4);                                                                \
+    p += c_ * 4;                                                                                   \
+  } while (0)
+  GET (row_ptr, (size_t)n + 1);
+  GET (edge_sym, E);
+  GET (edge_next, E);
+  GET (fail, n);
+  GET (depth, n);
+  GET (nb_outputs, n);
+  GET (term_kw, n);
+  GET (out_link, n);
+  GET (depth_start, (size_t)in.lmax + 2);
+  GET (kw_state, in.n_keywords);
+#undef GET
+  if (bad) {
+    acm_flat_release (f);
+    return ACM_GPU_E_NOMEM;
+  }
+  f->info = in;
+
+  /* ---- shape of the goto function: breadth-first numbering means edge e leads to state e + 1 */
+  int ok = f->row_ptr[0] == 0 && f->row_ptr[n] == E;
+  for (uint32_t s = 0; ok && s < n; s++)
+    ok = f->row_ptr[s] <= f->row_ptr[s + 1] && f->row_ptr[s + 1] <= E;
+  const uint64_t sym_limit = in.sym_bytes == 4 ? (1ull << 32) : (1ull << (8 * in.sym_bytes));
+  uint32_t lo = UINT32_MAX, hi = 0;
+  for (uint32_t s = 0; ok && s < n; s++)
+    for (uint32_t e = f->row_ptr[s]; ok && e < f->row_ptr[s + 1]; e++) {
+      ok = f->edge_next[e] == e + 1 && f->edge_sym[e] < sym_limit &&
+           (e == f->row_ptr[s] || f->edge_sym[e - 1] < f->edge_sym[e]);
+      if (f->edge_sym[e] < lo)
+        lo = f->edge_sym[e];
+      if (f->edge_sym[e] > hi)
+        hi = f->edge_sym[e];
+    }
+  /* ---- everything else is a function of (row_ptr, edge_sym, term_kw): recompute and compare */
+  uint32_t *parent = ok ? malloc ((size_t)n * 4) : NULL;
+  if (ok && !parent) {
+    acm_flat_release (f);
+    return ACM_GPU_E_NOMEM;
+  }
+  uint32_t lmax = 0, nkw = 0, max_out = 0;
+  if (ok) {
+    parent[0] = 0;
+    for (uint32_t s = 0; s < n; s++)
+      for (uint32_t e = f->row_ptr[s]; e < f->row_ptr[s + 1]; e++)
+        parent[e + 1] = s;
+    ok = f->depth[0] == 0 && f->fail[0] == 0 && f->out_link[0] == 0;
+    for (uint32_t s = 1; ok && s < n; s++) {
+      const uint32_t par = parent[s], c = f->edge_sym[s - 1];
+      ok = par < s && f->depth[s] == f->depth[par] + 1;
+      uint32_t fs = 0;
+      if (ok && par != 0) { /* f(s) = delta(f(parent), c); children of the root fail to the root */
+        uint32_t t = f->fail[par];
+        for (;;) {
+          const uint32_t ch = csr_child (f->row_ptr, f->edge_sym, t, c);
+          if (ch != UINT32_MAX) {
+            fs = ch;
+            break;
+          }
+          if (t == 0)
+            break;
+          t = f->fail[t];
+        }
+      }
+      ok = ok && f->fail[s] == fs && fs < s;
+      if (ok) {
+        const uint32_t want_link = fs == 0 ? 0 : (f->term_kw[fs] != UINT32_MAX ? fs : f->out_link[fs]);
+        ok = f->out_link[s] == want_link;
+      }
+    }
+    for (uint32_t s = 0; ok && s < n; s++) {
+      const uint32_t term = f->term_kw[s] != UINT32_MAX;
+      ok = (s != 0 || !term) && f->nb_outputs[s] == term + (s ? f->nb_outputs[f->fail[s]] : 0) &&
+           (!term || f->term_kw[s] < in.n_keywords);
+      if (s && f->depth[s] < f->depth[s - 1])
+        ok = 0;
+      if (f->depth[s] > lmax)
+        lmax = f->depth[s];
+      nkw += term;
+      if (f->nb_outputs[s] > max_out)
+        max_out = f->nb_outputs[s];
+    }
+    ok = ok && lmax == in.lmax && nkw == in.n_keywords && max_out == in.max_outputs;
+    /* keyword ids are a permutation of [0, K) and kw_state is its inverse */
+    for (uint32_t k = 0; ok && k < in.n_keywords; k++)
+      ok = f->kw_state[k] < n && f->term_kw[f->kw_state[k]] == k;
+    for (uint32_t d = 0, i = 0; ok && d <= lmax + 1; d++) {
+      while (i < n && f->depth[i] < d)
+        i++;
+      ok = f->depth_start[d] == i;
+    }
+    if (ok && E && in.sym_bytes == 1)
+      ok = in.alpha_lo == lo && in.alpha_span == hi - lo + 1 &&
+           in.width == (in.alpha_span == 256 ? 256u : in.alpha_span + 1);
+    else if (ok)
+      ok = in.alpha_lo == (E ? lo : 0) && in.alpha_span == 0 && in.width == (in.sym_bytes == 1 ? 1u : 0u);
+  }
+  free (parent);
+  if (!ok) {
+    acm_flat_release (f);
+    return ACM_GPU_E_FORMAT;
+  }
+  *out = f;
+  return ACM_GPU_OK;
+}
+
+int
+acm_flat_save (const ACMFlat *f, const char *path) {
+  if (!f || !path)
+    return ACM_GPU_E_ARG;
+  const size_t bytes = acm_flat_blob_bytes (f);
+  void *buf = malloc (bytes);
+  if (!buf)
+    return ACM_GPU_E_NOMEM;
+  int rc = acm_flat_to_blob (f, buf, bytes);
+  if (rc == ACM_GPU_OK) {
+    FILE *fp = fopen (path, "wb");
+    if (!fp || fwrite (buf, 1, bytes, fp) != bytes)
+      rc = ACM_GPU_E_IO;
+    if (fp && fclose (fp) != 0)
+      rc = ACM_GPU_E_IO;
+  }
+  free (buf);
+  return rc;
+}
+
+int
+acm_flat_load (const char *path, ACMFlat **out) {
+  if (!path || !out)
+    return ACM_GPU_E_ARG;
+  *out = NULL;
+  FILE *fp = fopen (path, "rb");
+  if (!fp)
+    return ACM_GPU_E_IO;
+  int rc = ACM_GPU_OK;
+  void *buf = NULL;
+  long len = -1;
+  if (fseek (fp, 0, SEEK_END) != 0 || (len = ftell (fp)) < 0 || fseek (fp, 0, SEEK_SET) != 0)
+    rc = ACM_GPU_E_IO;
+  if (rc == ACM_GPU_OK && !(buf = malloc (len ? (size_t)len : 1)))
+    rc = ACM_GPU_E_NOMEM;
+  if (rc == ACM_GPU_OK && fread (buf, 1, (size_t)len, fp) != (size_t)len)
+    rc = ACM_GPU_E_IO;
+  fclose (fp);
+  if (rc == ACM_GPU_OK)
+    rc = acm_flat_from_blob (buf, (size_t)len, out);
+  free (buf);
+  return rc;
+}
+
+/* Spelling of keyword kw_id read back from the tables alone (each state but the root has one
+ * incoming goto edge: edge e leads to state e + 1): `symbols` receives min(length, capacity)
+ * symbols of sym_bytes bytes each, front to back; *length the keyword's length.  This is what
+ * acm_get_match's letters[] spell (reference :472-479), for consumers that only hold a blob. */
+int
+acm_flat_keyword (const ACMFlat *f, uint32_t kw_id, void *symbols, uint32_t capacity, uint32_t *length) {
+  if (!f || kw_id >= f->info.n_keywords || (!symbols && capacity))
+    return ACM_GPU_E_ARG;
+  uint32_t s = f->kw_state[kw_id];
+  const uint32_t len = f->depth[s], sb = f->info.sym_bytes;
+  if (length)
+    *length = len;
+  for (uint32_t d = len; d > 0; d--) {
+    /* parent of s: the row that contains edge s - 1 */
+    const uint32_t e = s - 1;
+    if (d - 1 < capacity) {
+      const uint32_t v = f->edge_sym[e];
+      unsigned char *o = (unsigned char *)symbols + (size_t)(d - 1) * sb;
+      for (uint32_t i = 0; i < sb; i++)
+        o[i] = (unsigned char)(v >> (8 * i));
+    }
+    uint32_t lo = 0, hi = f->info.n_states; /* last s' with row_ptr[s'] <= e */
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (f->row_ptr[mid] <= e)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    s = lo;
+  }
   return ACM_GPU_OK;
 }

@@ -927,6 +927,8 @@ acm_gpu_strerror (int code) {
   case ACM_GPU_E_ARG: return "invalid argument";
   case ACM_GPU_E_NOMEM: return "out of memory";
   case ACM_GPU_E_INTERNAL: return "internal consistency check failed on the device";
+  case ACM_GPU_E_FORMAT: return "not a valid flat-table blob";
+  case ACM_GPU_E_IO: return "file could not be read or written";
   default: return "unknown error";
   }
 }

@@ -45,7 +45,9 @@ enum {
   ACM_GPU_E_OVERFLOW = -4,   /* more matches than `capacity`; the count output holds the number needed */
   ACM_GPU_E_ARG = -5,        /* invalid argument */
   ACM_GPU_E_NOMEM = -6,
-  ACM_GPU_E_INTERNAL = -7    /* a device-side consistency check failed (never expected) */
+  ACM_GPU_E_INTERNAL = -7,   /* a device-side consistency check failed (never expected) */
+  ACM_GPU_E_FORMAT = -8,     /* not a flat-table blob, wrong version, or its contents do not hold together */
+  ACM_GPU_E_IO = -9          /* a file could not be read or written */
 };
 const char *acm_gpu_strerror (int code);
 int acm_gpu_device_count (void);
@@ -98,6 +100,21 @@ void acm_flat_view (const ACMFlat *flat, ACMFlatView *view);
  * `span` (when width == span + 1) standing for every symbol outside [lo, lo + span).
  * entry_bytes is 2 (n_states <= 32768) or 4. */
 int acm_flat_dense_rows (const ACMFlat *flat, uint32_t n_rows, uint32_t entry_bytes, void *out);
+
+/* Serialised form of the flat tables (versioned, little-endian; layout in acm_flat.c).  The
+ * reference keeps a machine in memory only and rebuilds it from its keywords at every start; a
+ * blob restores the scan tables without the keywords or the trie.  Loading recomputes the failure
+ * function and every derived array from the goto function and compares: a blob that loads is what
+ * acm_flatten would have produced.  Values (`void *` of acm_insert_end_of_keyword) are process-
+ * local and not part of a blob; keyword ids and spellings are (acm_flat_keyword). */
+size_t acm_flat_blob_bytes (const ACMFlat *flat);
+int acm_flat_to_blob (const ACMFlat *flat, void *out, size_t capacity);
+int acm_flat_from_blob (const void *blob, size_t bytes, ACMFlat **out);
+int acm_flat_save (const ACMFlat *flat, const char *path);
+int acm_flat_load (const char *path, ACMFlat **out);
+/* Spelling of keyword `keyword_id` from the tables alone -- what MatchHolder.letters[] spell
+ * (aho_corasick.c:472-479): min(length, capacity) symbols of sym_bytes bytes each, front to back. */
+int acm_flat_keyword (const ACMFlat *flat, uint32_t keyword_id, void *symbols, uint32_t capacity, uint32_t *length);
 
 /* ------------------------------------------------------------------ device plan */
 typedef struct ACMPlan ACMPlan;

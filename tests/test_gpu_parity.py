@@ -346,3 +346,33 @@ def test_streaming_synthetic_large_pieces(torch_cuda):
     assert got.size == 35453 and po.digest(got) == 0x75c631ca92f2fd08
     assert np.all(np.diff(got["end_pos"].astype(np.int64)) >= 0)
     st.close()
+
+
+@pytest.mark.parametrize("name", ["ternary_dense", "u16_symbols"])
+def test_plan_from_loaded_blob(torch_cuda, name, tmp_path):
+    """A dictionary saved as a flat-table blob and loaded again (no machine, no keywords) scans
+    like the machine it came from; record keyword ids resolve to spellings through the blob."""
+    from aho_corasick_1975_amd import binding
+    kws, text, sym = CASES[name]
+    m, o = build_pair(kws, sym)
+    want = o.scan(text)
+    path = tmp_path / "dict.ac75"
+    m.flatten().save(path)
+    del m
+    loaded = binding.FlatTables.load(path)
+    got = loaded.plan(0).scan_sorted(_dev(torch_cuda, text))
+    assert np.array_equal(got, want)
+    assert want.size > 0
+    for r in got[:: max(1, got.size // 50)]:
+        assert loaded.keyword(int(r["keyword_id"])).size == int(r["length"])
+
+
+def test_config2_plan_from_blob_digest(torch_cuda):
+    from aho_corasick_1975_amd import binding
+    kd, ko = acm.synth.keywords(1000)
+    m = acm.Machine(1)
+    m.add_keywords_packed(kd, ko)
+    blob = m.flatten().to_bytes()
+    plan = binding.FlatTables.from_bytes(blob).plan(0)
+    got = plan.scan_sorted(acm.synth.device_text(1 << 26, kd, ko))
+    assert got.size == 35453 and po.digest(got) == 0x75c631ca92f2fd08
