@@ -194,8 +194,16 @@ def test_u32_config5_shape(torch_cuda):
     dev = acm.synth.device_text(n, kd, ko, sym_bytes=4)
     assert np.array_equal(dev.cpu().numpy().view(np.uint32), text)
     plan = m.plan(0)
-    assert plan.info.kernel == 2
-    assert np.array_equal(plan.scan_sorted(dev), o.scan(text))
+    assert plan.info.kernel == 3        # sparse kernel, root table in LDS
+    want = o.scan(text)
+    assert np.array_equal(plan.scan_sorted(dev), want)
+    # a buffer that is not 16-byte aligned takes the CSR kernel: same records
+    assert np.array_equal(plan.scan_sorted(dev[1:]), o.scan(text[1:]))
+    # shards with warm-up, odd lengths
+    for b, e in ((0, 1), (5, 77), (1000, 1000 + 4097), (4103, 4103 + 5000), (65536 + 7, 65536 + 7 + 100001), (n - 33, n)):
+        rb = max(b - (m.lmax - 1), 0)
+        got = plan.scan_sorted(dev[rb:e], emit_from=b - rb, pos_base=rb)
+        assert np.array_equal(got, want[(want["end_pos"] >= b) & (want["end_pos"] < e)])
 
 
 def test_100k_dictionary_config3_shape(torch_cuda):
