@@ -1075,6 +1075,339 @@ scan_sparse_kernel (SparseK K, EmitCtx E, Launch A, const unsigned char *__restr
   flush_queue<false, COUNT_ONLY> (E, queue, qn);
 }
 
+/* ------------------------------------------------------------------ start-parallel kernel (2- and 4-byte symbols)
+ * The same match set, computed without a state carried from symbol to symbol: a keyword occurs
+ * at [i, i + L) iff the goto function alone (the trie, no failure transitions) leads from the root
+ * through text[i .. i + L) to its terminal state.  With a large alphabet nearly every start dies
+ * at once, so instead of one dependent table lookup per symbol (the sparse walk above waits
+ * ~2.7 us of memory latency per step) every position is tested independently, in three sieves:
+ *   1. one LDS lookup per symbol in the root table: child state | ALWAYS << 31 | SECOND << 30
+ *      (SECOND: the symbol is the second symbol of some keyword).  A start survives if its
+ *      symbol has a child and the next symbol has SECOND (config 5: 7% of the positions);
+ *   2. the two smallest edge symbols of the child (8 bytes, a 69 KB table on config 5) against
+ *      the next symbol -- the load is issued at once and looked at one group (1 KiB of text)
+ *      later, so nobody waits for it.  Children that are keywords themselves or have more than
+ *      two edges carry ALWAYS and pass both sieves unseen;
+ *   3. what is left (config 5: 3 starts per 10,000 symbols) is queued per wave and walked down
+ *      the trie 64 at a time (walk_starts); terminal states give records (end position, depth,
+ *      keyword id).
+ * The text is read the coalesced way: a wave takes 1 KiB groups, lane l the 16 bytes at 16 l,
+ * four groups walked while the next four are in flight.  Every record belongs to the start
+ * position that finds it: nothing is warmed up, nothing is found twice.  Worst case (every start
+ * walks lmax symbols) is lmax dependent loads per symbol; ACM_GPU_SPARSE=walk selects the sparse
+ * automaton walk instead. */
+struct StartsK {
+  const uint4 *srec;   /* 2 x uint4 per state: {-, n_edges, edge_begin, terminal} {sym0, next0, sym1, next1} */
+  const uint2 *sedge;  /* per goto edge, rows in ascending symbol order: {symbol, next} */
+  const uint2 *pairs;  /* states 0 .. root fan-out: the symbols of the first two edges (repeated / 0 when fewer) */
+  const uint32_t *lut; /* by symbol value: child | SECOND << 30 | ALWAYS << 31 */
+  uint32_t lut_size;
+  uint32_t R;          /* groups per tile, a multiple of 4 */
+  uint32_t queue_off;  /* LDS: [lut if staged][16 queues of 128][16 hit buffers of 64][tile counter] */
+};
+constexpr uint32_t ST_ALWAYS = 0x80000000u, ST_SECOND = 0x40000000u, ST_STATE = 0x3FFFFFFFu;
+
+/* Matches found by a wave collect in its LDS hit buffer as (end position, terminal state) and
+ * leave 64 at a time: one atomic on the record counter per 64 records (one per find was 0.7 ms of
+ * serialised atomics on config 5: a single address sustains ~90 per microsecond). */
+__device__ __forceinline__ void
+flush_hits (const EmitCtx &E, const uint2 *hits, uint32_t n, uint32_t lane) {
+  unsigned long long base = 0;
+  if (lane == 0)
+    base = atomicAdd (E.count, (unsigned long long)n);
+  base = ((unsigned long long)__shfl ((uint32_t)(base >> 32), 0, WAVE) << 32) | __shfl ((uint32_t)base, 0, WAVE);
+  if (lane < n && base + lane < E.capacity) {
+    const uint2 h = hits[lane];
+    const uint4 oi = E.oinfo[h.y]; /* terminal state: its first output is its own keyword */
+    const uint64_t gp = E.pos_base + h.x;
+    *reinterpret_cast<uint4 *> (&E.records[base + lane]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), oi.z, oi.w);
+  }
+}
+
+/* tally: this lane's finds (count-only mode; summed over the wave at the end of the kernel) or
+ * the fill of the hit buffer (record mode, wave-uniform) */
+template <bool COUNT_ONLY>
+__device__ __forceinline__ void
+emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t lane, uint2 *hits, unsigned long long &tally) {
+  if (COUNT_ONLY) {
+    tally += hit ? 1u : 0u;
+    return;
+  }
+  const uint64_t m = __ballot (hit);
+  if (m) {
+    const uint32_t total = (uint32_t)__popcll (m);
+    uint32_t hn = (uint32_t)tally;
+    if (hn + total > WAVE) {
+      flush_hits (E, hits, hn, lane);
+      hn = 0;
+    }
+    if (hit)
+      hits[hn + (uint32_t)__popcll (m & ((1ull << lane) - 1))] = make_uint2 (p, st);
+    tally = hn + total;
+  }
+}
+
+/* third sieve: up to 64 queued starts, item = (position p of the first symbol, child of the root
+ * reached by it); walks the goto function from there while the text follows it */
+/* (the structs come by pointer to copies the caller makes on the spot: taking the address of
+ * the kernel's own K and E would move them from scalar registers to scratch memory for the whole
+ * kernel -- measured 2x on the main loop) */
+template <typename SYM, bool COUNT_ONLY>
+__device__ __noinline__ unsigned long long
+walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, const uint2 *items, uint32_t n_items, uint2 *hits,
+             unsigned long long counted) {
+  const StartsK &K = *Kp;
+  const EmitCtx &E = *Ep;
+  const uint32_t lane = lane_id ();
+  bool alive = lane < n_items;
+  const uint2 it = alive ? items[lane] : make_uint2 (0, 0);
+  uint32_t p = it.x, st = it.y;
+  uint4 ra = K.srec[2 * st], rb = K.srec[2 * st + 1];
+  bool more = alive && p + 1 < E.n;
+  uint32_t c1 = more ? (uint32_t)text[p + 1] : 0u;
+  for (;;) {
+    emit_terminals<COUNT_ONLY> (E, alive && ra.w != 0 && p >= E.emit_from, p, st, lane, hits, counted);
+    uint32_t nx = NONE;
+    if (alive && more) {
+      const uint32_t ne = ra.y;
+      if (ne >= 1 && rb.x == c1)
+        nx = rb.y;
+      else if (ne >= 2 && rb.z == c1)
+        nx = rb.w;
+      else if (ne > 2) {
+        uint32_t lo = ra.z, hi = ra.z + ne;
+        while (lo < hi) {
+          const uint32_t mid = lo + (hi - lo) / 2;
+          if (K.sedge[mid].x < c1)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        if (lo < ra.z + ne) {
+          const uint2 e = K.sedge[lo];
+          if (e.x == c1)
+            nx = e.y;
+        }
+      }
+    }
+    alive = alive && nx != NONE;
+    if (!__ballot (alive))
+      break;
+    if (alive) {
+      st = nx;
+      p++;
+      ra = K.srec[2 * st];
+      rb = K.srec[2 * st + 1];
+      more = p + 1 < E.n;
+      c1 = more ? (uint32_t)text[p + 1] : 0u;
+    }
+  }
+  return counted;
+}
+
+template <bool LUT_LDS>
+__device__ __forceinline__ uint32_t
+starts_root (const StartsK &K, uint32_t c) {
+  if (c < K.lut_size) {
+    if (LUT_LDS)
+      return *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (c * 4u);
+    return K.lut[c];
+  }
+  /* beyond the table: bisect the root row; no sieve can be applied, let everything pass */
+  const uint4 a = K.srec[0];
+  uint32_t lo = a.z, hi = a.z + a.y;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (K.sedge[mid].x < c)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo < a.z + a.y) {
+    const uint2 e = K.sedge[lo];
+    if (e.x == c)
+      return e.y | ST_SECOND | ST_ALWAYS;
+  }
+  return ST_SECOND;
+}
+
+/* a start between the first and the second sieve */
+struct PendingStart {
+  uint2 pair;     /* the child's first two edge symbols (load in flight) */
+  uint32_t ntok;  /* the symbol after the start */
+  uint32_t child; /* root-table entry of the start's symbol; 0 = none pending */
+  uint32_t pos;
+};
+
+template <typename SYM, bool LUT_LDS, bool COUNT_ONLY>
+__global__ __launch_bounds__ (SPARSE_THREADS) void
+scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text8) {
+  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
+  constexpr uint32_t PER = 16 / sizeof (SYM);  /* symbols per lane per group */
+  constexpr uint32_t PERW = 4 / sizeof (SYM);  /* symbols per 32-bit word */
+  constexpr uint32_t GROUP = WAVE * PER;
+  constexpr uint32_t SYM_MASK = sizeof (SYM) == 4 ? 0xFFFFFFFFu : (1u << (8 * (sizeof (SYM) & 3))) - 1u;
+  if (LUT_LDS) {
+    uint4 *dst = reinterpret_cast<uint4 *> (smem);
+    const uint4 *src = reinterpret_cast<const uint4 *> (K.lut);
+    for (uint32_t i = threadIdx.x; i < (K.lut_size + 3) / 4; i += blockDim.x)
+      dst[i] = src[i];
+  }
+  constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (QCAP + WAVE) * 8);
+  if (threadIdx.x == 0)
+    *next_tile = 0;
+  __syncthreads ();
+
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint32_t wib = uniform (threadIdx.x / WAVE);
+  uint2 *queue = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
+  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * WAVE;
+  const SYM *text = reinterpret_cast<const SYM *> (text8);
+  const uint4 *text16 = reinterpret_cast<const uint4 *> (text8);
+  const uint32_t ntiles = A.range_end - A.range_begin;
+  const uint32_t tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
+  const uint32_t blk_begin = blockIdx.x * tiles_per_block;
+  const uint32_t blk_tiles = blk_begin >= ntiles ? 0 : (ntiles - blk_begin < tiles_per_block ? ntiles - blk_begin : tiles_per_block);
+  const uint32_t last_blk = (uint32_t)(((uint64_t)A.n * sizeof (SYM) - 1) / 16);
+  uint32_t qn = 0;
+  unsigned long long counted = 0;
+  DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_cands = 0, d_deep = 0, d_tiles = 0;)
+  PendingStart pend[4][PERW];
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+#pragma unroll
+    for (uint32_t i = 0; i < PERW; i++)
+      pend[w][i].child = 0;
+
+  auto load_group = [&] (uint32_t g) -> uint4 {
+    const uint32_t blk = g * WAVE + lane;
+#ifdef ST_EXP_NT
+    typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+    const v4u v = __builtin_nontemporal_load (reinterpret_cast<const v4u *> (&text16[blk < last_blk ? blk : last_blk]));
+    return make_uint4 (v.x, v.y, v.z, v.w);
+#else
+    return text16[blk < last_blk ? blk : last_blk];
+#endif
+  };
+  /* second sieve on a start whose pair has arrived; survivors go to the wave's queue */
+  auto resolve = [&] (PendingStart &P) {
+    const bool deep = P.child != 0 && ((P.child & ST_ALWAYS) || P.pair.x == P.ntok || P.pair.y == P.ntok);
+    const uint64_t m = __ballot (deep);
+    if (m) {
+      if (deep)
+        queue[qn + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (P.pos, P.child & ST_STATE);
+      qn = uniform (qn + (uint32_t)__popcll (m));
+      if (qn >= WAVE) {
+        qn -= WAVE;
+        DIAG (const unsigned long long d_c0 = __builtin_readcyclecounter ();)
+        {
+          const StartsK Kc = K;
+          const EmitCtx Ec = E;
+          counted = walk_starts<SYM, COUNT_ONLY> (&Kc, &Ec, text, queue + qn, WAVE, hits, counted);
+          if (!COUNT_ONLY)
+            counted = uniform ((uint32_t)counted); /* fill of the hit buffer: one value for the wave */
+        }
+        DIAG (d_walk += __builtin_readcyclecounter () - d_c0; d_calls++;)
+      }
+    }
+    DIAG (d_cands += __popcll (__ballot (P.child != 0)); d_deep += __popcll (m);)
+    P.child = 0;
+  };
+  /* first sieve on the start at position p: e0 = entry of its symbol, e1 = entry of the next
+   * symbol (0 when there is none), ntok = the next symbol */
+  auto sieve = [&] (PendingStart &P, uint32_t e0, uint32_t e1, uint32_t ntok, uint32_t p) {
+    resolve (P); /* the start that used this slot one group ago */
+    /* (straight-line: every lane loads, the ones without a start pairs[0]; a load under a branch
+     * would make the compiler wait for everything in flight, prefetched text included) */
+    const bool cand = (e0 & ST_STATE) != 0 && ((e0 & ST_ALWAYS) || (e1 & ST_SECOND));
+    P.child = cand ? e0 : 0u;
+    P.pair = K.pairs[P.child & ST_STATE];
+    P.ntok = ntok;
+    P.pos = p;
+  };
+  /* one group: `cur` = this lane's 16 bytes, next_x = word 0 of every lane of the following group */
+  auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t g) {
+    const uint32_t pos0 = g * GROUP + lane * PER; /* position of this lane's first symbol */
+    /* word 0 of the next lane (of the next group for lane 63): holds the successor of this lane's last symbol */
+    uint32_t after = __shfl_down (cur.x, 1, WAVE);
+    const uint32_t after_group = uniform (next_x);
+    if (lane == WAVE - 1)
+      after = after_group;
+    const uint32_t words[5] = { cur.x, cur.y, cur.z, cur.w, after };
+    uint32_t e_first = pos0 < A.n ? starts_root<LUT_LDS> (K, cur.x & SYM_MASK) : 0u;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint32_t p = pos0 + w * PERW;
+      const uint32_t ntok_word = words[w + 1] & SYM_MASK;
+      const uint32_t e_next = p + PERW < A.n ? starts_root<LUT_LDS> (K, ntok_word) : 0u;
+      if (PERW == 2) {
+        const uint32_t mid = words[w] >> 16;
+        const uint32_t e_mid = p + 1 < A.n ? starts_root<LUT_LDS> (K, mid) : 0u;
+        sieve (pend[w][0], e_first, e_mid, mid, p);
+        sieve (pend[w][PERW - 1], e_mid, e_next, ntok_word, p + 1);
+      } else
+        sieve (pend[w][0], e_first, e_next, ntok_word, p);
+      e_first = e_next;
+    }
+  };
+
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0)
+      t = atomicAdd (next_tile, 1u);
+    t = uniform (t);
+    if (t >= blk_tiles)
+      break;
+    DIAG (d_tiles++;)
+    const uint32_t g0 = (A.range_begin + blk_begin + t) * K.R;
+    uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
+    for (uint32_t k = 0; k < K.R; k += 4) {
+      const uint32_t g = g0 + k;
+      const uint4 n0 = load_group (g + 4), n1 = load_group (g + 5), n2 = load_group (g + 6), n3 = load_group (g + 7);
+      walk_group (c0, c1.x, g);
+      walk_group (c1, c2.x, g + 1);
+      walk_group (c2, c3.x, g + 2);
+      walk_group (c3, n0.x, g + 3);
+      c0 = n0;
+      c1 = n1;
+      c2 = n2;
+      c3 = n3;
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+#pragma unroll
+    for (uint32_t i = 0; i < PERW; i++)
+      resolve (pend[w][i]);
+  if (qn) {
+    const StartsK Kc = K;
+    const EmitCtx Ec = E;
+    counted = walk_starts<SYM, COUNT_ONLY> (&Kc, &Ec, text, queue, qn, hits, counted);
+    if (!COUNT_ONLY)
+      counted = uniform ((uint32_t)counted);
+  }
+  if (COUNT_ONLY) {
+    const uint32_t incl = wave_incl_scan ((uint32_t)counted); /* a lane finds far fewer than 2^32 / 64 */
+    const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
+    if (lane == 0 && total)
+      atomicAdd (E.count, (unsigned long long)total);
+  } else if (counted)
+    flush_hits (E, hits, (uint32_t)counted, lane);
+  DIAG (if (lane == 0) {
+    const uint32_t wave = blockIdx.x * (SPARSE_THREADS / WAVE) + wib;
+    if (wave < 8192) {
+      unsigned long long *o = g_acm_diag[wave];
+      o[0] = __builtin_readcyclecounter () - d_t0;
+      o[1] = d_walk;
+      o[2] = d_calls;
+      o[3] = d_cands;
+      o[4] = d_deep;
+      o[5] = d_tiles;
+    }
+  })
+}
+
 /* ------------------------------------------------------------------ sort keys */
 __global__ void
 make_keys_kernel (const ACMRecord *rec, uint64_t n, uint32_t len_bits, uint64_t *keys) {
@@ -1133,8 +1466,10 @@ struct ACMPlan {
   const uint16_t *d_cont_dh = nullptr;
   /* sparse kernel (2- and 4-byte symbols) */
   SparseK SK{};
-  bool sparse = false, sparse_lut_lds = false;
-  uint32_t sparse_lds_bytes = 0;
+  StartsK TK{};
+  bool starts = false; /* start-parallel kernel instead of the sparse walk */
+  bool sparse = false, sparse_lut_lds = false, starts_lut_lds = false;
+  uint32_t sparse_lds_bytes = 0, starts_lds_bytes = 0;
   /* dense kernel (breadth-first numbering too: the LDS rows are a breadth-first prefix) */
   DenseK K{};
   const void *d_dense = nullptr;     /* failure-resolved rows of every state */
@@ -1225,6 +1560,21 @@ sparse_fn (bool lut_lds, bool count_only) {
 const void *
 sparse_kernel_ptr (uint32_t sym_bytes, bool lut_lds, bool count_only) {
   return sym_bytes == 2 ? sparse_fn<uint16_t> (lut_lds, count_only) : sparse_fn<uint32_t> (lut_lds, count_only);
+}
+
+template <typename SYM>
+const void *
+starts_fn (bool lut_lds, bool count_only) {
+  if (lut_lds)
+    return count_only ? reinterpret_cast<const void *> (&scan_starts_kernel<SYM, true, true>)
+                      : reinterpret_cast<const void *> (&scan_starts_kernel<SYM, true, false>);
+  return count_only ? reinterpret_cast<const void *> (&scan_starts_kernel<SYM, false, true>)
+                    : reinterpret_cast<const void *> (&scan_starts_kernel<SYM, false, false>);
+}
+
+const void *
+starts_kernel_ptr (uint32_t sym_bytes, bool lut_lds, bool count_only) {
+  return sym_bytes == 2 ? starts_fn<uint16_t> (lut_lds, count_only) : starts_fn<uint32_t> (lut_lds, count_only);
 }
 
 void
@@ -1327,6 +1677,12 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const size_t o_srec = blob_reserve (cur, sparse ? (size_t)n * 32 : 0);
   const size_t o_sedge = blob_reserve (cur, sparse ? (size_t)fi.n_edges * 8 : 0);
   const size_t o_lut = blob_reserve (cur, sparse ? (size_t)lut_size * 4 + 16 : 0);
+  /* the same three tables for the start-parallel kernel (flags mean something else there) */
+  const bool starts = sparse && n < 0x40000000u;
+  const size_t o_trec = blob_reserve (cur, starts ? (size_t)n * 32 : 0);
+  const size_t o_tedge = blob_reserve (cur, starts ? (size_t)fi.n_edges * 8 : 0);
+  const size_t o_tlut = blob_reserve (cur, starts ? (size_t)lut_size * 4 + 16 : 0);
+  const size_t o_tpairs = blob_reserve (cur, starts ? ((size_t)fv.row_ptr[1] + 1) * 8 : 0);
   p->blob_bytes = cur;
 
   std::vector<unsigned char> host (cur, 0);
@@ -1371,6 +1727,47 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     for (uint32_t e = 0; e < fv.row_ptr[1]; e++)
       if (fv.edge_sym[e] < lut_size)
         lut[fv.edge_sym[e]] = entry (e);
+  }
+  if (starts) {
+    uint32_t *rec = reinterpret_cast<uint32_t *> (&host[o_trec]);
+    uint32_t *edge = reinterpret_cast<uint32_t *> (&host[o_tedge]);
+    uint32_t *lut = reinterpret_cast<uint32_t *> (&host[o_tlut]);
+    uint32_t *pairs = reinterpret_cast<uint32_t *> (&host[o_tpairs]);
+    for (uint32_t e = 0; e < fi.n_edges; e++) {
+      edge[2 * e] = fv.edge_sym[e];
+      edge[2 * e + 1] = fv.edge_next[e];
+    }
+    for (uint32_t st = 0; st < n; st++) {
+      const uint32_t b = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b;
+      uint32_t *r = rec + 8 * (size_t)st;
+      r[0] = 0;
+      r[1] = ne;
+      r[2] = b;
+      r[3] = fv.term_kw[st] != NONE ? 1u : 0u;
+      r[4] = ne >= 1 ? fv.edge_sym[b] : 0;
+      r[5] = ne >= 1 ? fv.edge_next[b] : 0;
+      r[6] = ne >= 2 ? fv.edge_sym[b + 1] : 0;
+      r[7] = ne >= 2 ? fv.edge_next[b + 1] : 0;
+    }
+    const uint32_t root_edges = fv.row_ptr[1];
+    for (uint32_t st = 0; st <= root_edges; st++) {
+      const uint32_t b = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b;
+      pairs[2 * st] = ne >= 1 ? fv.edge_sym[b] : 0;
+      pairs[2 * st + 1] = ne >= 2 ? fv.edge_sym[b + 1] : pairs[2 * st];
+    }
+    for (uint32_t e = 0; e < root_edges; e++)
+      if (fv.edge_sym[e] < lut_size) {
+        const uint32_t child = fv.edge_next[e];
+        const uint32_t ne = fv.row_ptr[child + 1] - fv.row_ptr[child];
+        /* keyword by itself, more edges than the pair shows, or a pair that cannot be told
+         * from "no edge" (symbol 0 twice): never sieved out */
+        const bool always = fv.term_kw[child] != NONE || ne > 2 || ne == 0;
+        lut[fv.edge_sym[e]] = child | (always ? ST_ALWAYS : 0u);
+      }
+    /* second symbols: the edges that leave the root's children (states 1 .. root_edges) */
+    for (uint32_t e = fv.row_ptr[1]; e < fv.row_ptr[root_edges + 1]; e++)
+      if (fv.edge_sym[e] < lut_size)
+        lut[fv.edge_sym[e]] |= ST_SECOND;
   }
   if (dense) {
     int rc = acm_flat_dense_rows (flat, n, entry_bytes, &host[o_dense]);
@@ -1453,11 +1850,25 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     p->SK.queue_off = p->sparse_lut_lds ? lut_size * 4 : 0;
     p->SK.R = 0; /* per launch */
     p->sparse_lds_bytes = p->SK.queue_off + sparse_queue_bytes + 16;
+    const char *mode = getenv ("ACM_GPU_SPARSE");
+    p->starts = starts && !(mode && strcmp (mode, "walk") == 0);
+    if (starts) {
+      p->TK.srec = reinterpret_cast<const uint4 *> (b + o_trec);
+      p->TK.sedge = reinterpret_cast<const uint2 *> (b + o_tedge);
+      p->TK.lut = u32p (o_tlut);
+      p->TK.pairs = reinterpret_cast<const uint2 *> (b + o_tpairs);
+      p->TK.lut_size = lut_size;
+      const uint32_t starts_queue_bytes = (SPARSE_THREADS / WAVE) * (QCAP + WAVE) * 8;
+      p->starts_lut_lds = (uint64_t)lut_size * 4 + starts_queue_bytes + 16 <= lds_total;
+      p->TK.queue_off = p->starts_lut_lds ? lut_size * 4 : 0;
+      p->TK.R = 0;
+      p->starts_lds_bytes = p->TK.queue_off + starts_queue_bytes + 16;
+    }
   }
 
   ACMPlanInfo &I = p->info;
   I.device = device;
-  I.kernel = dense ? 1 : (sparse ? 3 : 2);
+  I.kernel = dense ? 1 : (sparse ? (p->starts ? 4 : 3) : 2);
   I.entry_bytes = dense ? entry_bytes : 0;
   I.width = fi.width;
   I.dense_rows = dense ? n : 0;
@@ -1471,14 +1882,18 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   I.table_bytes = cur;
 
   if (sparse) {
-    I.lds_bytes = p->sparse_lds_bytes;
+    I.lds_bytes = p->starts ? p->starts_lds_bytes : p->sparse_lds_bytes;
     I.block_threads = SPARSE_THREADS;
     I.grid_blocks = (uint32_t)p->cu_count;
-    I.streams = SPARSE_S;
+    I.streams = p->starts ? 1 : SPARSE_S;
     I.chunk_bytes = 128;
-    for (int co = 0; co < 2; co++)
+    for (int co = 0; co < 2; co++) {
       HIP_TRY (hipFuncSetAttribute (sparse_kernel_ptr (fi.sym_bytes, p->sparse_lut_lds, co != 0),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->sparse_lds_bytes));
+      if (p->starts)
+        HIP_TRY (hipFuncSetAttribute (starts_kernel_ptr (fi.sym_bytes, p->starts_lut_lds, co != 0),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->starts_lds_bytes));
+    }
   }
   if (dense) {
     for (int co = 0; co < 2; co++)
@@ -1619,6 +2034,35 @@ launch_sparse (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
   void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text };
   HIP_TRY (hipLaunchKernel (sparse_kernel_ptr (p->finfo.sym_bytes, p->sparse_lut_lds, COUNT_ONLY), dim3 (grid),
                             dim3 (SPARSE_THREADS), args, p->sparse_lds_bytes, st));
+  return ACM_GPU_OK;
+}
+
+template <bool COUNT_ONLY>
+int
+launch_starts (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
+  const uint32_t group = WAVE * (16 / p->finfo.sym_bytes); /* symbols per 1 KiB group */
+  const uint32_t ngroups = (uint32_t)(((uint64_t)a.n + group - 1) / group);
+  uint32_t grid = p->info.grid_blocks;
+  const uint32_t wpb = SPARSE_THREADS / WAVE;
+  /* a match that ends at emit_from or later starts no earlier than emit_from - (lmax - 1) */
+  const uint32_t back = p->finfo.lmax > 1 ? p->finfo.lmax - 1 : 0;
+  const uint32_t first_group = (a.emit_from > back ? a.emit_from - back : 0) / group;
+  /* groups per tile: about sixteen tiles per wave, 4 to 64 KiB each, a multiple of 4 */
+  uint64_t R = (ngroups - first_group) / ((uint64_t)grid * wpb * 16) & ~3ull;
+  if (R < 4)
+    R = 4;
+  if (R > 64)
+    R = 64;
+  StartsK K = p->TK;
+  K.R = (uint32_t)R;
+  a.range_begin = first_group / (uint32_t)R;
+  a.range_end = (uint32_t)((ngroups + R - 1) / R);
+  const uint32_t tiles = a.range_end - a.range_begin;
+  if ((tiles + wpb - 1) / wpb < grid)
+    grid = (tiles + wpb - 1) / wpb;
+  void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text };
+  HIP_TRY (hipLaunchKernel (starts_kernel_ptr (p->finfo.sym_bytes, p->starts_lut_lds, COUNT_ONLY), dim3 (grid),
+                            dim3 (SPARSE_THREADS), args, p->starts_lds_bytes, st));
   return ACM_GPU_OK;
 }
 
@@ -1792,7 +2236,9 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     else {
       a.range_begin = 0;
       a.range_end = a.n;
-      if (p->sparse && (reinterpret_cast<uintptr_t> (a.text) & 15) == 0)
+      if (p->starts && (reinterpret_cast<uintptr_t> (a.text) & 15) == 0)
+        rc = launch_starts<COUNT_ONLY> (p, E, a, st);
+      else if (p->sparse && (reinterpret_cast<uintptr_t> (a.text) & 15) == 0)
         rc = launch_sparse<COUNT_ONLY> (p, E, a, st);
       else
         rc = launch_csr<COUNT_ONLY> (p, E, a, st);

@@ -51,6 +51,20 @@ def test_small_cases_bit_exact(torch_cuda, name):
     assert np.array_equal(plan.scan_host(np.frombuffer(bytes(text), np.uint8) if isinstance(text, bytes) else text), want)
 
 
+@pytest.mark.parametrize("name", sorted(k for k in CASES if CASES[k][2] > 1))
+def test_wide_symbol_cases_sparse_walk(torch_cuda, monkeypatch, name):
+    """2- and 4-byte symbols through the sparse automaton walk (the default is the start-parallel
+    kernel, covered by test_small_cases_bit_exact)."""
+    monkeypatch.setenv("ACM_GPU_SPARSE", "walk")
+    kws, text, sym = CASES[name]
+    m, o = build_pair(kws, sym)
+    plan = m.plan(0)
+    assert plan.info.kernel == 3
+    want = o.scan(text)
+    assert np.array_equal(plan.scan_sorted(_dev(torch_cuda, text)), want)
+    assert int(plan.count(_dev(torch_cuda, text)).item()) == want.size
+
+
 def test_acm_scan_on_machine_follows_dictionary_updates(torch_cuda):
     """acm_scan() caches a plan inside the machine and rebuilds it when keywords were added."""
     m, o = build_pair([b"he", b"she"], 1)
@@ -185,8 +199,12 @@ def test_config2_full_size_properties(torch_cuda):
     assert head.size == 35453 and po.digest(head) == 0x75c631ca92f2fd08
 
 
-def test_u32_config5_shape(torch_cuda):
-    """BASELINE config 5 shape at test size: uint32 symbols, vocab 32,768, 10k keywords."""
+@pytest.mark.parametrize("mode", ["starts", "walk"])
+def test_u32_config5_shape(torch_cuda, monkeypatch, mode):
+    """BASELINE config 5 shape at test size: uint32 symbols, vocab 32,768, 10k keywords; both
+    kernels for large alphabets (start-parallel, and the sparse automaton walk)."""
+    if mode == "walk":
+        monkeypatch.setenv("ACM_GPU_SPARSE", "walk")
     kd, ko = acm.synth.keywords(10000, sym_bytes=4)
     m, o = build_pair_packed(kd, ko, sym_size=4)
     n = 1 << 20
@@ -194,7 +212,7 @@ def test_u32_config5_shape(torch_cuda):
     dev = acm.synth.device_text(n, kd, ko, sym_bytes=4)
     assert np.array_equal(dev.cpu().numpy().view(np.uint32), text)
     plan = m.plan(0)
-    assert plan.info.kernel == 3        # sparse kernel, root table in LDS
+    assert plan.info.kernel == (3 if mode == "walk" else 4)   # root table in LDS either way
     want = o.scan(text)
     assert np.array_equal(plan.scan_sorted(dev), want)
     # a buffer that is not 16-byte aligned takes the CSR kernel: same records
