@@ -11,6 +11,7 @@ _LIBNAME = "libac75_amd.so"
 RECORD_DTYPE = np.dtype([("end_pos", "<u8"), ("length", "<u4"), ("keyword_id", "<u4")])
 
 ACM_GPU_OK = 0
+ACM_GPU_E_INELIGIBLE = -1
 ACM_GPU_E_OVERFLOW = -4
 
 
@@ -47,7 +48,9 @@ class FlatInfo(C.Structure):
 
 class FlatView(C.Structure):
     _fields_ = [(n, C.POINTER(C.c_uint32)) for n in ("row_ptr", "edge_sym", "edge_next", "fail", "depth", "nb_outputs",
-                                                     "term_kw", "out_link", "depth_start", "kw_state")]
+                                                     "term_kw", "out_link", "depth_start", "kw_state")] + [
+        ("class_map", C.POINTER(C.c_uint16)), ("edge_letter", C.POINTER(C.c_uint32)), ("class_entries", C.c_uint32),
+        ("n_classes", C.c_uint32)]
 
 
 class PlanInfo(C.Structure):
@@ -65,7 +68,7 @@ EXPORTS = [
     "acm_matcher_release", "acm_nb_keywords", "acm_foreach_keyword", "acm_release", "acm_print",
     "acm_gpu_strerror", "acm_gpu_device_count", "acm_get_keyword", "acm_flatten", "acm_flat_release", "acm_flat_info", "acm_flat_view",
     "acm_flat_dense_rows", "acm_flat_blob_bytes", "acm_flat_to_blob", "acm_flat_from_blob", "acm_flat_save",
-    "acm_flat_load", "acm_flat_keyword", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_destroy",
+    "acm_flat_load", "acm_flat_keyword", "acm_flatten_classes", "acm_gpu_plan_create_classes", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_destroy",
     "acm_gpu_plan_info", "acm_gpu_scan_device", "acm_gpu_count_device", "acm_gpu_sort_tmp_bytes",
     "acm_gpu_sort_records_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
     "acm_gpu_plan_timing_read", "acm_gpu_plan_status", "acm_gpu_synth_text",
@@ -123,6 +126,10 @@ def lib():
     L.acm_flat_view.argtypes = [vp, C.POINTER(FlatView)]
     L.acm_flat_dense_rows.restype = i32
     L.acm_flat_dense_rows.argtypes = [vp, u32, u32, vp]
+    L.acm_flatten_classes.restype = i32
+    L.acm_flatten_classes.argtypes = [vp, u32, C.POINTER(vp)]
+    L.acm_gpu_plan_create_classes.restype = i32
+    L.acm_gpu_plan_create_classes.argtypes = [vp, u32, i32, C.POINTER(vp)]
     L.acm_flat_blob_bytes.restype = sz
     L.acm_flat_blob_bytes.argtypes = [vp]
     L.acm_flat_to_blob.restype = i32
@@ -208,6 +215,10 @@ class FlatTables:
         self.out_link = arr(v.out_link, n)
         self.depth_start = arr(v.depth_start, info.lmax + 2)
         self.kw_state = arr(v.kw_state, info.n_keywords)
+        # comparator-class machines (acm_flatten_classes): class table and the dictionary's own letters
+        self.n_classes = int(v.n_classes)
+        self.class_map = np.ctypeslib.as_array(v.class_map, shape=(v.class_entries,)).copy() if v.class_entries else None
+        self.edge_letter = arr(v.edge_letter, ne) if v.class_entries else None
 
     def dense_rows(self, n_rows=None, entry_bytes=None):
         info = self.info
@@ -272,15 +283,20 @@ class FlatTables:
 class Machine:
     """An ACMachine over fixed-size symbols compared with ACM_CMP_DEFAULT (reference
     aho_corasick.h:35,45), i.e. what `acm_create (ACM_CMP_DEFAULT, &(size_t){ sym_size }, 0)` returns.
-    Other comparators are available through the raw C API (lib())."""
+    With `cmp` (a C function pointer of type CMP_TYPE, e.g. ctypes.cast(lib.sym, c_void_p)) the
+    machine orders its alphabet with that comparator instead; such a machine reaches the GPU through
+    flatten_classes() / plan_classes() when its symbols are 1 or 2 bytes wide."""
 
-    def __init__(self, sym_size=1):
+    def __init__(self, sym_size=1, cmp=None, cmp_arg=None):
         L = lib()
         self.L = L
         self.sym_size = sym_size
-        self._arg = C.c_size_t(sym_size)
-        cmp_default = C.c_void_p.in_dll(L, "ACM_CMP_DEFAULT")
-        self.handle = L.acm_create(cmp_default, C.cast(C.pointer(self._arg), C.c_void_p), None)
+        self.custom_cmp = cmp is not None
+        if cmp is None:
+            self._arg = C.c_size_t(sym_size)
+            cmp = C.c_void_p.in_dll(L, "ACM_CMP_DEFAULT")
+            cmp_arg = C.cast(C.pointer(self._arg), C.c_void_p)
+        self.handle = L.acm_create(cmp, cmp_arg, None)
         self._keep = []  # letters must outlive the machine (reference aho_corasick.h:39-43)
         self.lmax = 0
 
@@ -372,6 +388,17 @@ class Machine:
     def plan(self, device=0):
         h = C.c_void_p()
         _check(self.L.acm_gpu_plan_create(self.handle, device, C.byref(h)), "acm_gpu_plan_create")
+        return Plan(h, self.sym_size)
+
+    # ---- machines with a custom comparator (acm_flatten_classes / acm_gpu_plan_create_classes)
+    def flatten_classes(self):
+        h = C.c_void_p()
+        _check(self.L.acm_flatten_classes(self.handle, self.sym_size, C.byref(h)), "acm_flatten_classes")
+        return FlatTables(h)
+
+    def plan_classes(self, device=0):
+        h = C.c_void_p()
+        _check(self.L.acm_gpu_plan_create_classes(self.handle, self.sym_size, device, C.byref(h)), "acm_gpu_plan_create_classes")
         return Plan(h, self.sym_size)
 
     def scan_host(self, text, capacity=None):

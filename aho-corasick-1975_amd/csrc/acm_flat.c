@@ -17,6 +17,10 @@ struct ACMFlat {
   ACMFlatInfo info;
   uint32_t *row_ptr, *edge_sym, *edge_next, *fail, *depth, *nb_outputs, *term_kw, *out_link;
   uint32_t *depth_start, *kw_state;
+  /* machines flattened over comparator classes (acm_flatten_classes): edge_sym holds class ids */
+  uint16_t *class_map;   /* [class_entries] symbol value -> class id; NULL for ACM_CMP_DEFAULT machines */
+  uint32_t *edge_letter; /* [n_edges] the dictionary's own symbol on each edge */
+  uint32_t class_entries, n_classes;
 };
 
 static uint32_t
@@ -71,17 +75,16 @@ acm_flat_release (ACMFlat *f) {
   free (f->out_link);
   free (f->depth_start);
   free (f->kw_state);
+  free (f->class_map);
+  free (f->edge_letter);
   free (f);
 }
 
-int
-acm_flatten (ACMachine *machine, ACMFlat **out) {
-  if (!machine || !out)
-    return ACM_GPU_E_ARG;
-  uint32_t sym_bytes = 0;
-  int rc = acm_internal_symbol_bytes (machine, &sym_bytes);
-  if (rc)
-    return rc;
+/* class_map != NULL: symbols are replaced by their comparator class (ownership of class_map
+ * passes to the flat tables on success) */
+static int
+flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint32_t class_entries, uint32_t n_classes,
+              ACMFlat **out) {
 
   acm_internal_lock (machine); /* writers are excluded while the snapshot is taken */
   const uint32_t n = acm_internal_nb_states (machine);
@@ -100,6 +103,11 @@ acm_flatten (ACMachine *machine, ACMFlat **out) {
   f->out_link = malloc ((size_t)n * sizeof (uint32_t));
   if (!f->row_ptr || !f->edge_sym || !f->edge_next || !f->fail || !f->depth || !f->nb_outputs || !f->term_kw || !f->out_link)
     goto nomem;
+  if (class_map) {
+    f->edge_letter = malloc ((size_t)(n ? n : 1) * sizeof (uint32_t));
+    if (!f->edge_letter)
+      goto nomem;
+  }
 
   /* breadth-first renumbering; the queue is `order` itself */
   uint32_t head = 0, tail = 0, edges = 0, lmax = 0, nkw = 0, max_out = 0;
@@ -112,11 +120,15 @@ acm_flatten (ACMachine *machine, ACMFlat **out) {
       struct _ac_state *k = s->kids[i];
       newid[k->id] = tail;
       f->edge_sym[edges] = symbol_value (k->letter, sym_bytes);
+      if (class_map) {
+        f->edge_letter[edges] = f->edge_sym[edges];
+        f->edge_sym[edges] = class_map[f->edge_sym[edges]];
+      }
       f->edge_next[edges] = tail;
       edges++;
       order[tail++] = k;
     }
-    if (sym_bytes > 1 && s->nkids > 1) {
+    if (sym_bytes > 1 && s->nkids > 1 && !class_map) { /* class ids already ascend in comparator order */
       /* the comparator orders multi-byte symbols by memcmp; the device bisects rows by numeric
        * value, so re-order this row (and the ids just handed out) by value */
       if (sort_row_by_value (f->edge_sym + f->row_ptr[head], order + f->edge_next[f->row_ptr[head]], s->nkids))
@@ -184,6 +196,9 @@ acm_flatten (ACMachine *machine, ACMFlat **out) {
   acm_internal_unlock (machine);
   free (order);
   free (newid);
+  f->class_map = class_map;
+  f->class_entries = class_map ? class_entries : 0;
+  f->n_classes = class_map ? n_classes : 0;
   *out = f;
   return ACM_GPU_OK;
 
@@ -193,6 +208,120 @@ nomem:
   free (newid);
   acm_flat_release (f);
   return ACM_GPU_E_NOMEM;
+}
+
+int
+acm_flatten (ACMachine *machine, ACMFlat **out) {
+  if (!machine || !out)
+    return ACM_GPU_E_ARG;
+  uint32_t sym_bytes = 0;
+  int rc = acm_internal_symbol_bytes (machine, &sym_bytes);
+  if (rc)
+    return rc;
+  return flatten_impl (machine, sym_bytes, NULL, 0, 0, out);
+}
+
+/* ------------------------------------------------------------------ comparator classes
+ * A machine built with another comparator than ACM_CMP_DEFAULT (the reference's flagship "any
+ * ordered alphabet", README.md:43-44; e.g. the case-insensitive alphacmp of generic_test.c:48-54)
+ * cannot tell some symbols apart.  For 1- and 2-byte symbols all 256 / 65,536 values are sorted
+ * with the machine's own comparator; runs of values that compare equal are the classes, numbered
+ * in comparator order.  The automaton is flattened over class ids and the device maps the text
+ * through the same table before it walks it (classmap kernel), so the walk compares the way the
+ * comparator does, symbol for symbol. */
+struct class_sort_ctx {
+  CMP_TYPE cmp;
+  void *arg;
+  uint32_t sym_bytes;
+};
+
+static int
+class_sort_cmp (const void *a, const void *b, void *ctxp) {
+  const struct class_sort_ctx *ctx = ctxp;
+  /* the comparator sees what a caller's letters look like: sym_bytes bytes of the value in memory */
+  const uint32_t va = *(const uint32_t *)a, vb = *(const uint32_t *)b;
+  unsigned char la[2] = { (unsigned char)va, (unsigned char)(va >> 8) };
+  unsigned char lb[2] = { (unsigned char)vb, (unsigned char)(vb >> 8) };
+  const int c = ctx->cmp (la, lb, ctx->arg);
+  if (c)
+    return c;
+  return va < vb ? -1 : va > vb; /* keep the sort deterministic inside a class */
+}
+
+int
+acm_flatten_classes (ACMachine *machine, uint32_t sym_bytes, ACMFlat **out) {
+  if (!machine || !out || (sym_bytes != 1 && sym_bytes != 2))
+    return ACM_GPU_E_ARG;
+  struct class_sort_ctx ctx;
+  ctx.sym_bytes = sym_bytes;
+  acm_internal_comparator (machine, &ctx.cmp, &ctx.arg);
+  const uint32_t V = sym_bytes == 1 ? 256u : 65536u;
+  uint32_t *order = malloc ((size_t)V * sizeof *order);
+  uint16_t *class_map = malloc ((size_t)V * sizeof *class_map);
+  if (!order || !class_map) {
+    free (order);
+    free (class_map);
+    return ACM_GPU_E_NOMEM;
+  }
+  for (uint32_t v = 0; v < V; v++)
+    order[v] = v;
+  qsort_r (order, V, sizeof *order, class_sort_cmp, &ctx);
+  /* classes = runs of equal neighbours; a comparator that is not a consistent order over all
+   * values (sorted neighbours out of order either way) cannot be canonicalised */
+  uint32_t n_classes = 0;
+  int consistent = 1;
+  for (uint32_t i = 0; i < V && consistent; i++) {
+    if (i == 0)
+      class_map[order[0]] = 0;
+    else {
+      const uint32_t a = order[i - 1], b = order[i];
+      unsigned char la[2] = { (unsigned char)a, (unsigned char)(a >> 8) };
+      unsigned char lb[2] = { (unsigned char)b, (unsigned char)(b >> 8) };
+      const int ab = ctx.cmp (la, lb, ctx.arg), ba = ctx.cmp (lb, la, ctx.arg);
+      if (ab > 0 || ba < 0 || (ab == 0) != (ba == 0))
+        consistent = 0;
+      if (ab < 0)
+        n_classes++;
+      class_map[b] = (uint16_t)n_classes;
+    }
+  }
+  n_classes++;
+  /* the sort only looked at neighbours: check the class representatives against one another too
+   * (all pairs up to 1024 classes, pairs at power-of-two distances beyond), and every value
+   * against the representative of its class */
+  if (consistent) {
+    uint32_t *rep = malloc ((size_t)n_classes * sizeof *rep);
+    if (!rep) {
+      free (order);
+      free (class_map);
+      return ACM_GPU_E_NOMEM;
+    }
+    for (uint32_t i = V; i-- > 0;)
+      rep[class_map[order[i]]] = order[i];
+    for (uint32_t v = 0; v < V && consistent; v++) {
+      const uint32_t r = rep[class_map[v]];
+      unsigned char lv[2] = { (unsigned char)v, (unsigned char)(v >> 8) };
+      unsigned char lr[2] = { (unsigned char)r, (unsigned char)(r >> 8) };
+      consistent = ctx.cmp (lv, lr, ctx.arg) == 0 && ctx.cmp (lr, lv, ctx.arg) == 0;
+    }
+    for (uint32_t i = 0; i < n_classes && consistent; i++)
+      for (uint32_t step = 1; i + step < n_classes && consistent; step = n_classes <= 1024 ? step + 1 : step * 2) {
+        const uint32_t a = rep[i], b = rep[i + step];
+        unsigned char la[2] = { (unsigned char)a, (unsigned char)(a >> 8) };
+        unsigned char lb[2] = { (unsigned char)b, (unsigned char)(b >> 8) };
+        consistent = ctx.cmp (la, lb, ctx.arg) < 0 && ctx.cmp (lb, la, ctx.arg) > 0;
+      }
+    free (rep);
+  }
+  free (order);
+  if (!consistent) {
+    free (class_map);
+    return ACM_GPU_E_INELIGIBLE;
+  }
+  int rc = flatten_impl (machine, sym_bytes, class_map, V, n_classes, out);
+  if (rc)
+    free (class_map);
+  return rc;
 }
 
 void
@@ -212,6 +341,10 @@ acm_flat_view (const ACMFlat *f, ACMFlatView *v) {
   v->out_link = f->out_link;
   v->depth_start = f->depth_start;
   v->kw_state = f->kw_state;
+  v->class_map = f->class_map;
+  v->edge_letter = f->edge_letter;
+  v->class_entries = f->class_entries;
+  v->n_classes = f->n_classes;
 }
 
 /* Failure-resolved rows.  Row 0: goto or stay at the root.  Row s > 0: copy of row f(s) (already
@@ -258,10 +391,12 @@ acm_flat_dense_rows (const ACMFlat *f, uint32_t n_rows, uint32_t entry_bytes, vo
  * start).  A blob is the flat tables verbatim:
  *
  *   header, 80 bytes: "AC75FLAT" | u32 version (1) | u32 0x01020304 (byte-order probe) |
- *                     ACMFlatInfo (9 x u32) | u32 0 | u64 payload bytes | u64 FNV-1a-64 of payload |
- *                     u64 0
+ *                     ACMFlatInfo (9 x u32) | u32 class-table entries (0, 256 or 65536) |
+ *                     u64 payload bytes | u64 FNV-1a-64 of payload | u64 0
  *   payload, u32 arrays in this order: row_ptr[n+1] edge_sym[E] edge_next[E] fail[n] depth[n]
  *                     nb_outputs[n] term_kw[n] out_link[n] depth_start[lmax+2] kw_state[K]
+ *                     and for comparator-class machines: class_map (u16, entries / 2 words)
+ *                     edge_letter[E]
  *
  * Loading trusts nothing: the goto function (row_ptr, edge_sym, term_kw) is checked for shape,
  * every other array -- the failure function included -- is recomputed from it and compared.  A
@@ -280,14 +415,14 @@ fnv1a64 (const unsigned char *p, size_t n) {
 }
 
 static size_t
-blob_payload_words (const ACMFlatInfo *in) {
+blob_payload_words (const ACMFlatInfo *in, uint32_t class_entries) {
   const size_t n = in->n_states, e = in->n_edges;
-  return (n + 1) + 2 * e + 5 * n + ((size_t)in->lmax + 2) + in->n_keywords;
+  return (n + 1) + 2 * e + 5 * n + ((size_t)in->lmax + 2) + in->n_keywords + (class_entries ? class_entries / 2 + e : 0);
 }
 
 size_t
 acm_flat_blob_bytes (const ACMFlat *f) {
-  return f ? BLOB_HEADER + 4 * blob_payload_words (&f->info) : 0;
+  return f ? BLOB_HEADER + 4 * blob_payload_words (&f->info, f->class_entries) : 0;
 }
 
 int
@@ -311,10 +446,14 @@ acm_flat_to_blob (const ACMFlat *f, void *out, size_t capacity) {
   PUT (f->out_link, in->n_states);
   PUT (f->depth_start, (size_t)in->lmax + 2);
   PUT (f->kw_state, in->n_keywords);
+  if (f->class_entries) {
+    PUT (f->class_map, f->class_entries / 2);
+    PUT (f->edge_letter, in->n_edges);
+  }
 #undef PUT
   const uint64_t payload = (uint64_t)(p - (b + BLOB_HEADER));
   const uint64_t sum = fnv1a64 (b + BLOB_HEADER, (size_t)payload);
-  const uint32_t version = BLOB_VERSION, probe = 0x01020304u, zero = 0;
+  const uint32_t version = BLOB_VERSION, probe = 0x01020304u, zero = f->class_entries;
   const uint64_t zero64 = 0;
   memcpy (b, BLOB_MAGIC, 8);
   memcpy (b + 8, &version, 4);
@@ -347,7 +486,7 @@ acm_flat_from_blob (const void *blob, size_t bytes, ACMFlat **out) {
     return ACM_GPU_E_ARG;
   *out = NULL;
   const unsigned char *b = blob;
-  uint32_t version, probe;
+  uint32_t version, probe, class_entries;
   uint64_t payload, sum;
   ACMFlatInfo in;
   if (bytes < BLOB_HEADER || memcmp (b, BLOB_MAGIC, 8) != 0)
@@ -355,6 +494,7 @@ acm_flat_from_blob (const void *blob, size_t bytes, ACMFlat **out) {
   memcpy (&version, b + 8, 4);
   memcpy (&probe, b + 12, 4);
   memcpy (&in, b + 16, sizeof in);
+  memcpy (&class_entries, b + 52, 4);
   memcpy (&payload, b + 56, 8);
   memcpy (&sum, b + 64, 8);
   if (version != BLOB_VERSION || probe != 0x01020304u)
@@ -362,7 +502,9 @@ acm_flat_from_blob (const void *blob, size_t bytes, ACMFlat **out) {
   if (in.n_states == 0 || in.n_edges != in.n_states - 1 || in.n_keywords > in.n_states ||
       in.lmax >= in.n_states + 1 || (in.sym_bytes != 1 && in.sym_bytes != 2 && in.sym_bytes != 4))
     return ACM_GPU_E_FORMAT;
-  if (payload != 4ull * blob_payload_words (&in) || bytes - BLOB_HEADER < payload ||
+  if (class_entries != 0 && !(class_entries == 256 && in.sym_bytes == 1) && !(class_entries == 65536 && in.sym_bytes == 2))
+    return ACM_GPU_E_FORMAT;
+  if (payload != 4ull * blob_payload_words (&in, class_entries) || bytes - BLOB_HEADER < payload ||
       fnv1a64 (b + BLOB_HEADER, (size_t)payload) != sum)
     return ACM_GPU_E_FORMAT;
 
@@ -392,12 +534,22 @@ acm_flat_from_blob (const void *blob, size_t bytes, ACMFlat **out) {
   GET (out_link, n);
   GET (depth_start, (size_t)in.lmax + 2);
   GET (kw_state, in.n_keywords);
+  if (class_entries) {
+    f->class_map = malloc ((size_t)class_entries * 2);
+    if (!f->class_map)
+      bad = 1;
+    else
+      memcpy (f->class_map, p, (size_t)class_entries * 2);
+    p += (size_t)class_entries * 2;
+    GET (edge_letter, E);
+  }
 #undef GET
   if (bad) {
     acm_flat_release (f);
     return ACM_GPU_E_NOMEM;
   }
   f->info = in;
+  f->class_entries = class_entries;
 
   /* ---- shape of the goto function: breadth-first numbering means edge e leads to state e + 1 */
   int ok = f->row_ptr[0] == 0 && f->row_ptr[n] == E;
@@ -478,6 +630,26 @@ acm_flat_from_blob (const void *blob, size_t bytes, ACMFlat **out) {
       ok = in.alpha_lo == (E ? lo : 0) && in.alpha_span == 0 && in.width == (in.sym_bytes == 1 ? 1u : 0u);
   }
   free (parent);
+  if (ok && class_entries) {
+    /* class ids are dense from 0, and every edge carries the class of its own letter */
+    uint32_t top = 0;
+    for (uint32_t v = 0; v < class_entries; v++)
+      if (f->class_map[v] > top)
+        top = f->class_map[v];
+    f->n_classes = top + 1;
+    unsigned char *seen = calloc (f->n_classes, 1);
+    if (!seen) {
+      acm_flat_release (f);
+      return ACM_GPU_E_NOMEM;
+    }
+    for (uint32_t v = 0; v < class_entries; v++)
+      seen[f->class_map[v]] = 1;
+    for (uint32_t c = 0; ok && c < f->n_classes; c++)
+      ok = seen[c];
+    free (seen);
+    for (uint32_t e = 0; ok && e < E; e++)
+      ok = f->edge_letter[e] < class_entries && f->class_map[f->edge_letter[e]] == f->edge_sym[e];
+  }
   if (!ok) {
     acm_flat_release (f);
     return ACM_GPU_E_FORMAT;
@@ -546,7 +718,7 @@ acm_flat_keyword (const ACMFlat *f, uint32_t kw_id, void *symbols, uint32_t capa
     /* parent of s: the row that contains edge s - 1 */
     const uint32_t e = s - 1;
     if (d - 1 < capacity) {
-      const uint32_t v = f->edge_sym[e];
+      const uint32_t v = f->edge_letter ? f->edge_letter[e] : f->edge_sym[e]; /* the dictionary's own spelling */
       unsigned char *o = (unsigned char *)symbols + (size_t)(d - 1) * sb;
       for (uint32_t i = 0; i < sb; i++)
         o[i] = (unsigned char)(v >> (8 * i));

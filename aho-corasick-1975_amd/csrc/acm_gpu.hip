@@ -1408,6 +1408,37 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
   })
 }
 
+/* ------------------------------------------------------------------ comparator classes
+ * Plans of machines flattened over comparator classes (acm_flatten_classes) map the text to
+ * class ids first: one table of 65,536 16-bit entries in LDS serves both symbol sizes -- 2-byte
+ * symbols index it directly, bytes go through it two at a time ((class(hi) << 8) | class(lo)), so
+ * either way it is one ds_read_u16 per two bytes of text. */
+__global__ __launch_bounds__ (1024) void
+classmap_kernel (const uint4 *__restrict__ in, uint4 *__restrict__ out, uint64_t n_blocks16, const uint16_t *__restrict__ lut) {
+  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
+  {
+    uint4 *dst = reinterpret_cast<uint4 *> (smem);
+    const uint4 *src = reinterpret_cast<const uint4 *> (lut);
+    for (uint32_t i = threadIdx.x; i < 65536 * 2 / 16; i += blockDim.x)
+      dst[i] = src[i];
+  }
+  __syncthreads ();
+  const uint16_t *l = reinterpret_cast<const uint16_t *> (smem);
+  auto map2 = [&] (uint32_t w) -> uint32_t { return (uint32_t)l[w & 0xFFFFu] | ((uint32_t)l[w >> 16] << 16); };
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks16; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 v = in[i];
+    out[i] = make_uint4 (map2 (v.x), map2 (v.y), map2 (v.z), map2 (v.w));
+  }
+}
+
+/* element-wise form for the last bytes of a buffer and for buffers that are not 16-byte aligned */
+template <typename SYM>
+__global__ void
+classmap_tail_kernel (const SYM *__restrict__ in, SYM *__restrict__ out, uint64_t begin, uint64_t n, const uint16_t *__restrict__ lut) {
+  for (uint64_t i = begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    out[i] = (SYM)lut[in[i]]; /* a byte v indexes entry (0 << 8) | v: class(v) in its low byte */
+}
+
 /* ------------------------------------------------------------------ sort keys */
 __global__ void
 make_keys_kernel (const ACMRecord *rec, uint64_t n, uint32_t len_bits, uint64_t *keys) {
@@ -1484,6 +1515,10 @@ struct ACMPlan {
   unsigned long long *d_total = nullptr; /* [0] running total of a scan, [1] low word = expand ticket; zero between scans */
   unsigned int *d_pool_ctr = nullptr;    /* 2 x POOL_CLASSES tile-pool counters (same allocation), alternating per launch */
   uint32_t launch_seq = 0;
+  /* comparator-class plans: the text is mapped to class ids into d_remap before every scan */
+  uint16_t *d_classlut = nullptr;
+  void *d_remap = nullptr;
+  size_t remap_bytes = 0;
   uint32_t regions = 0, region_items = 0;
   uint64_t segment = SEGMENT;
   uint64_t generation = 0; /* for the machine-cached plan */
@@ -1900,6 +1935,22 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       HIP_TRY (hipFuncSetAttribute (dense_kernel_ptr (entry_bytes, p->chunk, p->streams, co != 0),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)I.lds_bytes));
   }
+  if (fv.class_map) {
+    /* 65,536 entries either way: 2-byte symbols directly, bytes in pairs (see classmap_kernel) */
+    std::vector<uint16_t> lut (65536);
+    if (fi.sym_bytes == 1) {
+      for (uint32_t v = 0; v < 65536; v++)
+        lut[v] = (uint16_t)((fv.class_map[v >> 8] << 8) | (fv.class_map[v & 255] & 255));
+    } else
+      memcpy (lut.data (), fv.class_map, 65536 * 2);
+    if (hipMalloc (reinterpret_cast<void **> (&p->d_classlut), 65536 * 2) != hipSuccess ||
+        hipMemcpy (p->d_classlut, lut.data (), 65536 * 2, hipMemcpyHostToDevice) != hipSuccess) {
+      acm_gpu_plan_destroy (p);
+      return ACM_GPU_E_NOMEM;
+    }
+    HIP_TRY (hipFuncSetAttribute (reinterpret_cast<const void *> (&classmap_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2));
+  }
   *out = p;
   return ACM_GPU_OK;
 }
@@ -1908,6 +1959,17 @@ extern "C" int
 acm_gpu_plan_create (ACMachine *machine, int device, ACMPlan **out) {
   ACMFlat *flat = nullptr;
   int rc = acm_flatten (machine, &flat);
+  if (rc)
+    return rc;
+  rc = acm_gpu_plan_create_flat (flat, device, out);
+  acm_flat_release (flat);
+  return rc;
+}
+
+extern "C" int
+acm_gpu_plan_create_classes (ACMachine *machine, uint32_t sym_bytes, int device, ACMPlan **out) {
+  ACMFlat *flat = nullptr;
+  int rc = acm_flatten_classes (machine, sym_bytes, &flat);
   if (rc)
     return rc;
   rc = acm_gpu_plan_create_flat (flat, device, out);
@@ -1932,6 +1994,10 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
     (void)hipFree (plan->d_fill);
   if (plan->d_total)
     (void)hipFree (plan->d_total);
+  if (plan->d_classlut)
+    (void)hipFree (plan->d_classlut);
+  if (plan->d_remap)
+    (void)hipFree (plan->d_remap);
   delete plan;
 }
 
@@ -2178,6 +2244,46 @@ launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
   return ACM_GPU_OK;
 }
 
+/* maps n symbols of d_text to class ids into the plan's own buffer (grown as needed) */
+int
+classmap_text (ACMPlan *p, const void *d_text, uint64_t n, hipStream_t st) {
+  const uint32_t sb = p->finfo.sym_bytes;
+  const size_t bytes = (size_t)n * sb;
+  if (p->remap_bytes < bytes + 16) {
+    if (p->d_remap) {
+      HIP_TRY (hipStreamSynchronize (st)); /* an earlier scan may still read the old buffer */
+      HIP_TRY (hipFree (p->d_remap));
+      p->d_remap = nullptr;
+      p->remap_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 4096;
+    if (hipMalloc (&p->d_remap, want) != hipSuccess)
+      return ACM_GPU_E_NOMEM;
+    p->remap_bytes = want;
+  }
+  const bool aligned = (reinterpret_cast<uintptr_t> (d_text) & 15) == 0;
+  const uint64_t blocks16 = aligned ? bytes / 16 : 0;
+  if (blocks16) {
+    const uint64_t want_blocks = (blocks16 + 1023) / 1024;
+    const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)p->cu_count ? want_blocks : (uint64_t)p->cu_count);
+    hipLaunchKernelGGL (classmap_kernel, dim3 (grid), dim3 (1024), 65536 * 2, st, static_cast<const uint4 *> (d_text),
+                        static_cast<uint4 *> (p->d_remap), blocks16, p->d_classlut);
+  }
+  const uint64_t done = blocks16 * 16 / sb;
+  if (done < n) {
+    const uint64_t left = n - done;
+    const uint32_t grid = (uint32_t)((left + 255) / 256 < 4096 ? (left + 255) / 256 : 4096);
+    if (sb == 1)
+      hipLaunchKernelGGL ((classmap_tail_kernel<uint8_t>), dim3 (grid), dim3 (256), 0, st, static_cast<const uint8_t *> (d_text),
+                          static_cast<uint8_t *> (p->d_remap), done, n, p->d_classlut);
+    else
+      hipLaunchKernelGGL ((classmap_tail_kernel<uint16_t>), dim3 (grid), dim3 (256), 0, st, static_cast<const uint16_t *> (d_text),
+                          static_cast<uint16_t *> (p->d_remap), done, n, p->d_classlut);
+  }
+  HIP_TRY (hipGetLastError ());
+  return ACM_GPU_OK;
+}
+
 template <bool COUNT_ONLY>
 int
 scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint64_t pos_base, ACMRecord *d_records,
@@ -2186,11 +2292,19 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
    * running total keeps counting and is handed over by acm_gpu_stream_finish, not here */
   HIP_TRY (hipSetDevice (p->device));
   const uint32_t sb = p->finfo.sym_bytes;
-  const bool use_dense = p->info.kernel == 1 && (reinterpret_cast<uintptr_t> (d_text) & 15) == 0;
+  /* (a comparator-class plan walks its own aligned copy of the text) */
+  const bool use_dense = p->info.kernel == 1 && (p->d_classlut || (reinterpret_cast<uintptr_t> (d_text) & 15) == 0);
   if (!accumulate && (n == 0 || p->finfo.n_edges == 0 || emit_from >= n || !use_dense))
     HIP_TRY (hipMemsetAsync (d_count, 0, sizeof (uint64_t), st));
   if (n == 0 || p->finfo.n_edges == 0 || emit_from >= n)
     return ACM_GPU_OK;
+  if (p->d_classlut) {
+    /* comparator-class plan: walk the class ids of the text (our own, aligned, copy) */
+    int rc = classmap_text (p, d_text, n, st);
+    if (rc)
+      return rc;
+    d_text = p->d_remap;
+  }
   if (use_dense) {
     int rc = ensure_item_buffer (p, n < p->segment ? n : p->segment);
     if (rc)

@@ -87,6 +87,11 @@ acm_internal_symbol_bytes (const ACMachine *m, uint32_t *sym_bytes) {
   return ACM_GPU_OK;
 }
 void
+acm_internal_comparator (const ACMachine *m, CMP_TYPE *cmp, void **cmp_arg) {
+  *cmp = m->cmp;
+  *cmp_arg = m->cmp_arg;
+}
+void
 acm_internal_lock (ACMachine *m) {
   ACM_REQUIRE (mtx_lock (&m->lock) == thrd_success, "");
 }

@@ -89,9 +89,22 @@ typedef struct {
   const uint32_t *out_link;    /* [n_states] nearest keyword-terminal state strictly down the failure chain, 0 if none */
   const uint32_t *depth_start; /* [lmax + 2] first state id of each depth; depth_start[lmax + 1] = n_states */
   const uint32_t *kw_state;    /* [n_keywords] terminal state of each keyword */
+  /* comparator-class machines only (acm_flatten_classes), else NULL / 0 */
+  const uint16_t *class_map;   /* [class_entries] symbol value -> class id: what edge_sym holds, and what the text is mapped through */
+  const uint32_t *edge_letter; /* [n_edges] the dictionary's own symbol on each edge (what MatchHolder.letters[] point at) */
+  uint32_t class_entries;      /* 256 or 65536 */
+  uint32_t n_classes;
 } ACMFlatView;
 
 int acm_flatten (ACMachine *machine, ACMFlat **out);
+/* Machines created with another comparator than ACM_CMP_DEFAULT (aho_corasick.h:33,45; e.g. the
+ * case-insensitive alphacmp of generic_test.c:48-54) over symbols of sym_bytes = 1 or 2 bytes: the
+ * comparator is called on all 256 / 65,536 symbol values to find the classes of symbols it cannot
+ * tell apart; the tables are built over class ids and a plan made from them maps the text through
+ * the class table on the device before walking it.  ACM_GPU_E_INELIGIBLE if the comparator is not
+ * a consistent order over all values.  (The symbol size is an argument because a custom
+ * comparator's cmp_arg is opaque.) */
+int acm_flatten_classes (ACMachine *machine, uint32_t sym_bytes, ACMFlat **out);
 void acm_flat_release (ACMFlat *flat);
 void acm_flat_info (const ACMFlat *flat, ACMFlatInfo *info);
 void acm_flat_view (const ACMFlat *flat, ACMFlatView *view);
@@ -142,6 +155,10 @@ typedef struct {
  * inserted later are not seen by it. */
 int acm_gpu_plan_create (ACMachine *machine, int device, ACMPlan **out);
 int acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out);
+/* acm_flatten_classes + acm_gpu_plan_create_flat: plan of a machine with a custom comparator over
+ * 1- or 2-byte symbols.  Scans of such a plan first map the text to class ids (one more pass over
+ * the text into a buffer the plan owns), then run the same kernels. */
+int acm_gpu_plan_create_classes (ACMachine *machine, uint32_t sym_bytes, int device, ACMPlan **out);
 void acm_gpu_plan_destroy (ACMPlan *plan);
 void acm_gpu_plan_info (const ACMPlan *plan, ACMPlanInfo *info);
 

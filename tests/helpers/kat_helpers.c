@@ -46,3 +46,40 @@ kat_read_novel (const char *path, wchar_t *out, long cap) {
   fclose (f);
   return n;
 }
+
+/* comparators for the comparator-class path (1- and 2-byte symbols): the byte / UTF-16-unit
+ * analogues of kat_alphacmp, and one whose classes interleave over the value range */
+int
+kat_casecmp8 (const void *a, const void *b, const void *arg) {
+  (void)arg;
+  unsigned x = *(const unsigned char *)a, y = *(const unsigned char *)b;
+  if (x >= 'A' && x <= 'Z')
+    x += 32;
+  if (y >= 'A' && y <= 'Z')
+    y += 32;
+  return x > y ? 1 : (x < y ? -1 : 0);
+}
+
+int
+kat_casecmp16 (const void *a, const void *b, const void *arg) {
+  (void)arg;
+  wint_t x = towlower ((wint_t) * (const unsigned short *)a), y = towlower ((wint_t) * (const unsigned short *)b);
+  return x > y ? 1 : (x < y ? -1 : 0);
+}
+
+int
+kat_mod7cmp8 (const void *a, const void *b, const void *arg) {
+  (void)arg;
+  unsigned x = *(const unsigned char *)a % 7u, y = *(const unsigned char *)b % 7u;
+  return x > y ? 1 : (x < y ? -1 : 0);
+}
+
+/* not an order: a < b < c < a */
+int
+kat_cyclic_cmp8 (const void *a, const void *b, const void *arg) {
+  (void)arg;
+  unsigned x = *(const unsigned char *)a % 3u, y = *(const unsigned char *)b % 3u;
+  if (x == y)
+    return 0;
+  return (x + 1) % 3 == y ? -1 : 1;
+}

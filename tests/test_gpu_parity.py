@@ -402,3 +402,66 @@ def test_config2_plan_from_blob_digest(torch_cuda):
     plan = binding.FlatTables.from_bytes(blob).plan(0)
     got = plan.scan_sorted(acm.synth.device_text(1 << 26, kd, ko))
     assert got.size == 35453 and po.digest(got) == 0x75c631ca92f2fd08
+
+
+def _fn_ptr(kat, name):
+    import ctypes as C
+    return C.cast(getattr(kat, name), C.c_void_p)
+
+
+def test_case_insensitive_comparator_on_the_gpu(torch_cuda, kat, novel_bytes):
+    """Comparator classes: the reference's case-insensitive matching
+    (generic_test.c:48-54) with byte symbols -- the device maps the text through the class table,
+    then walks it with the dense kernel; records equal the oracle's with the same comparator."""
+    kws = [b"He", b"SHE", b"his", b"hErs"]
+    m = acm.Machine(1, cmp=_fn_ptr(kat, "kat_casecmp8"))
+    o = po.Oracle(1, po.MEYER85, cmp=_fn_ptr(kat, "kat_casecmp8"))
+    for kw in kws:
+        m.add_keyword(kw)
+        o.add_keyword(kw)
+    plan = m.plan_classes(0)
+    assert plan.info.kernel == 1
+    want = o.scan(novel_bytes)
+    assert want.size > 11676
+    dev = _dev(torch_cuda, novel_bytes)
+    assert np.array_equal(plan.scan_sorted(dev), want)
+    assert int(plan.count(dev).item()) == want.size
+    # unaligned buffers, odd lengths, shards with warm-up
+    for b, e in ((1, 7), (3, 100001), (77, 12345), (len(novel_bytes) - 9, len(novel_bytes))):
+        rb = max(b - 3, 0)
+        got = plan.scan_sorted(dev[rb:e], emit_from=b - rb, pos_base=rb)
+        assert np.array_equal(got, want[(want["end_pos"] >= b) & (want["end_pos"] < e)])
+    # streaming pieces go through the same mapping
+    st = plan.stream(max_piece_symbols=50000, record_capacity=1 << 16)
+    host = np.frombuffer(novel_bytes, np.uint8)
+    for off in range(0, host.size, 50000):
+        st.feed(host[off:off + 50000])
+    assert np.array_equal(st.finish(), want)
+    st.close()
+
+
+def test_interleaved_classes_and_u16_on_the_gpu(torch_cuda, kat):
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    kws = [bytes(rng.integers(0, 256, size=rng.integers(1, 6)).astype(np.uint8)) for _ in range(60)]
+    m = acm.Machine(1, cmp=_fn_ptr(kat, "kat_mod7cmp8"))
+    o = po.Oracle(1, po.MEYER85, cmp=_fn_ptr(kat, "kat_mod7cmp8"))
+    for kw in kws:
+        m.add_keyword(kw)
+        o.add_keyword(kw)
+    text = rng.integers(0, 256, size=300001).astype(np.uint8)
+    plan = m.plan_classes(0)
+    assert np.array_equal(plan.scan_sorted(_dev(torch_cuda, text)), o.scan(text))
+    # 2-byte symbols, case-insensitive over UTF-16 units
+    kws16 = [np.array([ord(c) for c in w], np.uint16) for w in ("Été", "STRASSE", "naïve", "Ωmega", "x")]
+    m16 = acm.Machine(2, cmp=_fn_ptr(kat, "kat_casecmp16"))
+    o16 = po.Oracle(2, po.MEYER85, cmp=_fn_ptr(kat, "kat_casecmp16"))
+    for kw in kws16:
+        m16.add_keyword(kw)
+        o16.add_keyword(kw)
+    text16 = np.array([ord(c) for c in "l'été ÉTÉ Strasse straße NAÏVE ωMEGA ΩMEGa xX " * 999], np.uint16)
+    plan16 = m16.plan_classes(0)
+    want16 = o16.scan(text16)
+    assert want16.size >= 999 * 8
+    assert np.array_equal(plan16.scan_sorted(_dev(torch_cuda, text16)), want16)
+    assert np.array_equal(plan16.scan_sorted(_dev(torch_cuda, text16)[1:]), o16.scan(text16[1:]))
