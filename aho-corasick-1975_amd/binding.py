@@ -68,7 +68,7 @@ EXPORTS = [
     "acm_matcher_release", "acm_nb_keywords", "acm_foreach_keyword", "acm_release", "acm_print",
     "acm_gpu_strerror", "acm_gpu_device_count", "acm_get_keyword", "acm_flatten", "acm_flat_release", "acm_flat_info", "acm_flat_view",
     "acm_flat_dense_rows", "acm_flat_blob_bytes", "acm_flat_to_blob", "acm_flat_from_blob", "acm_flat_save",
-    "acm_flat_load", "acm_flat_keyword", "acm_flatten_classes", "acm_gpu_plan_create_classes", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_destroy",
+    "acm_flat_load", "acm_flat_keyword", "acm_flatten_classes", "acm_gpu_plan_create_classes", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_update", "acm_gpu_plan_destroy",
     "acm_gpu_plan_info", "acm_gpu_scan_device", "acm_gpu_count_device", "acm_gpu_sort_tmp_bytes",
     "acm_gpu_sort_records_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
     "acm_gpu_plan_timing_read", "acm_gpu_plan_status", "acm_gpu_synth_text",
@@ -144,6 +144,8 @@ def lib():
     L.acm_flat_keyword.argtypes = [vp, u32, vp, u32, C.POINTER(u32)]
     L.acm_gpu_plan_create.restype = i32
     L.acm_gpu_plan_create.argtypes = [vp, i32, C.POINTER(vp)]
+    L.acm_gpu_plan_update.restype = i32
+    L.acm_gpu_plan_update.argtypes = [vp, vp]
     L.acm_gpu_plan_create_flat.restype = i32
     L.acm_gpu_plan_create_flat.argtypes = [vp, i32, C.POINTER(vp)]
     L.acm_gpu_plan_destroy.restype = None
@@ -437,6 +439,11 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+    def update(self, machine):
+        """acm_gpu_plan_update(): take over the keywords added to `machine` since this plan was made."""
+        _check(lib().acm_gpu_plan_update(self.h, machine.handle), "acm_gpu_plan_update")
+        lib().acm_gpu_plan_info(self.h, C.byref(self.info))
 
     def describe(self):
         i = self.info

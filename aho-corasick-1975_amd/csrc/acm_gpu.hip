@@ -1439,6 +1439,20 @@ classmap_tail_kernel (const SYM *__restrict__ in, SYM *__restrict__ out, uint64_
     out[i] = (SYM)lut[in[i]]; /* a byte v indexes entry (0 << 8) | v: class(v) in its low byte */
 }
 
+/* ------------------------------------------------------------------ incremental updates
+ * word patches for the tables of the start-parallel kernel: {table, index, value, -} */
+struct PatchTables {
+  uint32_t *t[5];
+};
+__global__ void
+patch_kernel (PatchTables T, const uint4 *__restrict__ patches, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint4 q = patches[i];
+    T.t[q.x][q.y] = q.z;
+  }
+}
+
 /* ------------------------------------------------------------------ sort keys */
 __global__ void
 make_keys_kernel (const ACMRecord *rec, uint64_t n, uint32_t len_bits, uint64_t *keys) {
@@ -1485,6 +1499,40 @@ synth_text_kernel (SYM *text, uint64_t n, uint64_t gbegin, uint32_t vocab, const
 } // namespace
 
 /* ====================================================================== host side */
+/* Host mirror of the start-parallel tables of a plan that takes incremental updates
+ * (acm_gpu_plan_update).  The start-parallel kernel walks the goto function only -- no failure
+ * links, no output counts -- so a new keyword touches just the states on its own path: the new
+ * ones are appended (ids in order of creation after the breadth-first ids of the plan's build),
+ * the state they hang off gets one more edge, and the root table / pair table entries of at most
+ * two symbols change.  The changed words are collected as patches and written by patch_kernel on
+ * the stream of the next scan, in front of it. */
+enum { PT_REC = 0, PT_EDGE = 1, PT_LUT = 2, PT_PAIRS = 3, PT_OINFO = 4 };
+struct StartsMirror {
+  std::vector<uint32_t> tab[5];           /* rec: 8 per state, edge: 2 per slot, lut, pairs: 2 per state, oinfo: 4 per state */
+  std::vector<uint32_t> parent, parent_sym, depth; /* host only, per state */
+  uint32_t *dev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+  size_t cap[5] = { 0, 0, 0, 0, 0 };      /* device capacity in words */
+  bool own = false;                       /* device arrays of their own (else still inside the plan's blob) */
+  bool full_upload = false;
+  std::vector<uint4> patches;
+  uint4 *d_patches = nullptr;
+  size_t cap_patches = 0;
+  uint32_t n_states = 0, lmax = 0, n_keywords = 0, n_edges = 0;
+
+  void
+  set (int t, size_t idx, uint32_t v) {
+    if (idx >= tab[t].size ())
+      tab[t].resize (idx + 1, 0);
+    if (tab[t][idx] == v)
+      return;
+    tab[t][idx] = v;
+    if (idx >= cap[t] || !own)
+      full_upload = true; /* beyond what the device holds (or still in the blob): everything goes up again */
+    else if (!full_upload)
+      patches.push_back (make_uint4 ((uint32_t)t, (uint32_t)idx, v, 0));
+  }
+};
+
 struct ACMPlan {
   int device = 0;
   ACMFlatInfo finfo{};
@@ -1499,6 +1547,8 @@ struct ACMPlan {
   SparseK SK{};
   StartsK TK{};
   bool starts = false; /* start-parallel kernel instead of the sparse walk */
+  StartsMirror *mir = nullptr; /* starts plans: what acm_gpu_plan_update edits */
+  uint32_t class_sym_bytes = 0; /* comparator-class plans: the symbol size they were made for */
   bool sparse = false, sparse_lut_lds = false, starts_lut_lds = false;
   uint32_t sparse_lds_bytes = 0, starts_lds_bytes = 0;
   /* dense kernel (breadth-first numbering too: the LDS rows are a breadth-first prefix) */
@@ -1717,7 +1767,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const size_t o_trec = blob_reserve (cur, starts ? (size_t)n * 32 : 0);
   const size_t o_tedge = blob_reserve (cur, starts ? (size_t)fi.n_edges * 8 : 0);
   const size_t o_tlut = blob_reserve (cur, starts ? (size_t)lut_size * 4 + 16 : 0);
-  const size_t o_tpairs = blob_reserve (cur, starts ? ((size_t)fv.row_ptr[1] + 1) * 8 : 0);
+  const size_t o_tpairs = blob_reserve (cur, starts ? (size_t)n * 8 : 0); /* by state id; filled for the root's children */
   p->blob_bytes = cur;
 
   std::vector<unsigned char> host (cur, 0);
@@ -1785,6 +1835,15 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       r[7] = ne >= 2 ? fv.edge_next[b + 1] : 0;
     }
     const uint32_t root_edges = fv.row_ptr[1];
+    {
+      /* the root's row in the edge table: only the symbols the root table cannot hold (the tail
+       * of the sorted row; usually nothing) -- the table itself answers for the others */
+      uint32_t beyond = 0;
+      while (beyond < root_edges && fv.edge_sym[root_edges - 1 - beyond] >= lut_size)
+        beyond++;
+      rec[1] = beyond;
+      rec[2] = root_edges - beyond;
+    }
     for (uint32_t st = 0; st <= root_edges; st++) {
       const uint32_t b = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b;
       pairs[2 * st] = ne >= 1 ? fv.edge_sym[b] : 0;
@@ -1898,6 +1957,41 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       p->TK.queue_off = p->starts_lut_lds ? lut_size * 4 : 0;
       p->TK.R = 0;
       p->starts_lds_bytes = p->TK.queue_off + starts_queue_bytes + 16;
+      if (p->starts) {
+        StartsMirror *M = new (std::nothrow) StartsMirror ();
+        if (M) {
+          auto words = [&] (size_t off, size_t cnt) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *> (&host[off]);
+            return std::vector<uint32_t> (w, w + cnt);
+          };
+          M->tab[PT_REC] = words (o_trec, (size_t)n * 8);
+          M->tab[PT_EDGE] = words (o_tedge, (size_t)fi.n_edges * 2);
+          M->tab[PT_LUT] = words (o_tlut, lut_size);
+          M->tab[PT_PAIRS] = words (o_tpairs, (size_t)n * 2);
+          M->tab[PT_OINFO] = words (o_oinfo, (size_t)n * 4);
+          M->parent.assign (n, 0);
+          M->parent_sym.assign (n, 0);
+          M->depth.assign (fv.depth, fv.depth + n);
+          for (uint32_t st = 0; st < n; st++) {
+            M->tab[PT_REC][8 * (size_t)st] = st ? fv.row_ptr[st + 1] - fv.row_ptr[st] : M->tab[PT_REC][1]; /* row capacity = its size */
+            for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++) {
+              M->parent[fv.edge_next[e]] = st;
+              M->parent_sym[fv.edge_next[e]] = fv.edge_sym[e];
+            }
+          }
+          M->dev[PT_REC] = reinterpret_cast<uint32_t *> (b + o_trec);
+          M->dev[PT_EDGE] = reinterpret_cast<uint32_t *> (b + o_tedge);
+          M->dev[PT_LUT] = reinterpret_cast<uint32_t *> (b + o_tlut);
+          M->dev[PT_PAIRS] = reinterpret_cast<uint32_t *> (b + o_tpairs);
+          M->dev[PT_OINFO] = reinterpret_cast<uint32_t *> (b + o_oinfo);
+          M->cap[PT_LUT] = lut_size;
+          M->n_states = n;
+          M->n_edges = fi.n_edges;
+          M->n_keywords = fi.n_keywords;
+          M->lmax = fi.lmax;
+          p->mir = M;
+        }
+      }
     }
   }
 
@@ -1974,6 +2068,8 @@ acm_gpu_plan_create_classes (ACMachine *machine, uint32_t sym_bytes, int device,
     return rc;
   rc = acm_gpu_plan_create_flat (flat, device, out);
   acm_flat_release (flat);
+  if (!rc)
+    (*out)->class_sym_bytes = sym_bytes;
   return rc;
 }
 
@@ -1994,6 +2090,15 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
     (void)hipFree (plan->d_fill);
   if (plan->d_total)
     (void)hipFree (plan->d_total);
+  if (plan->mir) {
+    if (plan->mir->own)
+      for (int t = 0; t < 5; t++)
+        if (t != PT_LUT && plan->mir->dev[t])
+          (void)hipFree (plan->mir->dev[t]);
+    if (plan->mir->d_patches)
+      (void)hipFree (plan->mir->d_patches);
+    delete plan->mir;
+  }
   if (plan->d_classlut)
     (void)hipFree (plan->d_classlut);
   if (plan->d_remap)
@@ -2244,11 +2349,223 @@ launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
   return ACM_GPU_OK;
 }
 
+/* ---- incremental updates of a start-parallel plan */
+/* brings the device tables in line with the mirror, on the stream of the scan that follows */
+int
+starts_flush (ACMPlan *p, hipStream_t st) {
+  StartsMirror &M = *p->mir;
+  if (M.full_upload) {
+    /* (re)allocate with headroom and send everything; scans already enqueued still read the
+     * old arrays, so wait for them before those are freed */
+    HIP_TRY (hipDeviceSynchronize ());
+    uint32_t *fresh[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    size_t want[5];
+    for (int t = 0; t < 5; t++) {
+      if (t == PT_LUT)
+        continue; /* fixed size, stays in the plan's blob */
+      want[t] = M.tab[t].size () * 2 + 4096;
+      const bool keep = M.own && M.cap[t] >= M.tab[t].size ();
+      if (keep)
+        fresh[t] = M.dev[t];
+      else if (hipMalloc (reinterpret_cast<void **> (&fresh[t]), want[t] * 4) != hipSuccess ||
+               hipMemset (fresh[t], 0, want[t] * 4) != hipSuccess) { /* words never set are 0 in the mirror too */
+        for (int u = 0; u <= t; u++)
+          if (fresh[u] && fresh[u] != M.dev[u])
+            (void)hipFree (fresh[u]);
+        return ACM_GPU_E_NOMEM;
+      }
+    }
+    for (int t = 0; t < 5; t++) {
+      if (t == PT_LUT) {
+        HIP_TRY (hipMemcpy (M.dev[t], M.tab[t].data (), M.tab[t].size () * 4, hipMemcpyHostToDevice));
+        continue;
+      }
+      HIP_TRY (hipMemcpy (fresh[t], M.tab[t].data (), M.tab[t].size () * 4, hipMemcpyHostToDevice));
+      if (fresh[t] != M.dev[t]) {
+        if (M.own && M.dev[t])
+          HIP_TRY (hipFree (M.dev[t]));
+        M.dev[t] = fresh[t];
+        M.cap[t] = want[t];
+      }
+    }
+    M.own = true;
+    M.full_upload = false;
+    M.patches.clear ();
+    p->TK.srec = reinterpret_cast<const uint4 *> (M.dev[PT_REC]);
+    p->TK.sedge = reinterpret_cast<const uint2 *> (M.dev[PT_EDGE]);
+    p->TK.pairs = reinterpret_cast<const uint2 *> (M.dev[PT_PAIRS]);
+    p->d_oinfo = reinterpret_cast<const uint4 *> (M.dev[PT_OINFO]);
+    return ACM_GPU_OK;
+  }
+  if (M.patches.empty ())
+    return ACM_GPU_OK;
+  /* a word may have been set several times since the last flush and the patch kernel writes in
+   * no particular order: every patch carries the word's final value */
+  for (uint4 &q : M.patches)
+    q.z = M.tab[q.x][q.y];
+  const size_t np = M.patches.size ();
+  if (M.cap_patches < np) {
+    if (M.d_patches) {
+      HIP_TRY (hipStreamSynchronize (st));
+      HIP_TRY (hipFree (M.d_patches));
+      M.d_patches = nullptr;
+    }
+    M.cap_patches = np * 2 + 1024;
+    if (hipMalloc (reinterpret_cast<void **> (&M.d_patches), M.cap_patches * sizeof (uint4)) != hipSuccess) {
+      M.cap_patches = 0;
+      return ACM_GPU_E_NOMEM;
+    }
+  }
+  /* (blocking copy ordered on the stream: the staging vector can be reused at once, and an
+   * earlier patch kernel that reads d_patches has finished before it is overwritten) */
+  HIP_TRY (hipMemcpyWithStream (M.d_patches, M.patches.data (), np * sizeof (uint4), hipMemcpyHostToDevice, st));
+  PatchTables T;
+  for (int t = 0; t < 5; t++)
+    T.t[t] = M.dev[t];
+  hipLaunchKernelGGL (patch_kernel, dim3 ((uint32_t)((np + 255) / 256)), dim3 (256), 0, st, T, M.d_patches, (uint32_t)np);
+  HIP_TRY (hipGetLastError ());
+  M.patches.clear ();
+  return ACM_GPU_OK;
+}
+
+/* goto edge of mirror state s on symbol c (NONE if there is none) */
+uint32_t
+mirror_child (const StartsMirror &M, uint32_t s, uint32_t c) {
+  const uint32_t *r = &M.tab[PT_REC][8 * (size_t)s];
+  const uint32_t ne = r[1];
+  if (s == 0 && c < M.tab[PT_LUT].size ()) /* the root table answers for the symbols it holds */
+    return (M.tab[PT_LUT][c] & ST_STATE) ? (M.tab[PT_LUT][c] & ST_STATE) : NONE;
+  if (ne <= 2 && s != 0) {
+    if (ne >= 1 && r[4] == c)
+      return r[5];
+    if (ne >= 2 && r[6] == c)
+      return r[7];
+    return NONE;
+  }
+  uint32_t lo = r[2], hi = r[2] + ne;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (M.tab[PT_EDGE][2 * (size_t)mid] < c)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo < r[2] + ne && M.tab[PT_EDGE][2 * (size_t)lo] == c ? M.tab[PT_EDGE][2 * (size_t)lo + 1] : NONE;
+}
+
+/* root-table entry of the root's child `child` (its flags follow from its record) */
+void
+mirror_refresh_root_child (StartsMirror &M, uint32_t child) {
+  const uint32_t sym = M.parent_sym[child];
+  const uint32_t *r = &M.tab[PT_REC][8 * (size_t)child];
+  const uint32_t ne = r[1];
+  const bool always = r[3] != 0 || ne > 2 || ne == 0;
+  M.set (PT_PAIRS, 2 * (size_t)child, ne >= 1 ? r[4] : 0);
+  M.set (PT_PAIRS, 2 * (size_t)child + 1, ne >= 2 ? r[6] : (ne >= 1 ? r[4] : 0));
+  if (sym < M.tab[PT_LUT].size ())
+    M.set (PT_LUT, sym, (M.tab[PT_LUT][sym] & ST_SECOND) | child | (always ? ST_ALWAYS : 0u));
+}
+
+/* adds the edge s --c--> nx: rows stay sorted; states with more than two edges (and the root)
+ * keep theirs in the edge table, in a slot range with room to grow */
+void
+mirror_add_edge (StartsMirror &M, uint32_t s, uint32_t c, uint32_t nx) {
+  if (s == 0 && c < M.tab[PT_LUT].size ()) { /* the root-table entry (mirror_refresh_root_child) is the edge */
+    M.n_edges++;
+    return;
+  }
+  const size_t R = 8 * (size_t)s;
+  const uint32_t ne = M.tab[PT_REC][R + 1];
+  std::vector<std::pair<uint32_t, uint32_t>> row;
+  row.reserve (ne + 1);
+  if (ne <= 2 && s != 0) {
+    if (ne >= 1)
+      row.emplace_back (M.tab[PT_REC][R + 4], M.tab[PT_REC][R + 5]);
+    if (ne >= 2)
+      row.emplace_back (M.tab[PT_REC][R + 6], M.tab[PT_REC][R + 7]);
+  } else {
+    const uint32_t b = M.tab[PT_REC][R + 2];
+    for (uint32_t e = 0; e < ne; e++)
+      row.emplace_back (M.tab[PT_EDGE][2 * (size_t)(b + e)], M.tab[PT_EDGE][2 * (size_t)(b + e) + 1]);
+  }
+  row.insert (std::upper_bound (row.begin (), row.end (), std::make_pair (c, 0u),
+                                [] (const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first < b.first; }),
+              std::make_pair (c, nx));
+  const uint32_t nn = ne + 1;
+  if (nn > 2 || s == 0) {
+    uint32_t begin = M.tab[PT_REC][R + 2], capacity = M.tab[PT_REC][R + 0];
+    if (capacity < nn || (ne <= 2 && s != 0)) { /* no slots yet, or no room: a new range at the end */
+      capacity = nn * 2 > 4 ? nn * 2 : 4;
+      begin = (uint32_t)(M.tab[PT_EDGE].size () / 2);
+      M.tab[PT_EDGE].resize ((size_t)(begin + capacity) * 2, 0);
+      if ((size_t)(begin + capacity) * 2 > M.cap[PT_EDGE])
+        M.full_upload = true;
+      M.set (PT_REC, R + 0, capacity);
+      M.set (PT_REC, R + 2, begin);
+    }
+    for (uint32_t e = 0; e < nn; e++) {
+      M.set (PT_EDGE, 2 * (size_t)(begin + e), row[e].first);
+      M.set (PT_EDGE, 2 * (size_t)(begin + e) + 1, row[e].second);
+    }
+  }
+  M.set (PT_REC, R + 1, nn);
+  M.set (PT_REC, R + 4, row[0].first);
+  M.set (PT_REC, R + 5, row[0].second);
+  M.set (PT_REC, R + 6, nn >= 2 ? row[1].first : 0);
+  M.set (PT_REC, R + 7, nn >= 2 ? row[1].second : 0);
+  M.n_edges++;
+}
+
+/* one new keyword: symbols[0 .. len), keyword id kw */
+void
+mirror_insert (StartsMirror &M, const uint32_t *symbols, uint32_t len, uint32_t kw) {
+  uint32_t s = 0;
+  for (uint32_t i = 0; i < len; i++) {
+    const uint32_t c = symbols[i];
+    uint32_t nx = mirror_child (M, s, c);
+    if (nx == NONE) {
+      nx = M.n_states++;
+      M.parent.push_back (s);
+      M.parent_sym.push_back (c);
+      M.depth.push_back (i + 1);
+      for (int w = 0; w < 8; w++)
+        M.set (PT_REC, 8 * (size_t)nx + w, 0);
+      if (M.tab[PT_REC].size () < 8 * (size_t)(nx + 1))
+        M.tab[PT_REC].resize (8 * (size_t)(nx + 1), 0);
+      if (M.tab[PT_PAIRS].size () < 2 * (size_t)(nx + 1))
+        M.tab[PT_PAIRS].resize (2 * (size_t)(nx + 1), 0);
+      if (M.tab[PT_OINFO].size () < 4 * (size_t)(nx + 1))
+        M.tab[PT_OINFO].resize (4 * (size_t)(nx + 1), 0);
+      if (8 * (size_t)(nx + 1) > M.cap[PT_REC] || 2 * (size_t)(nx + 1) > M.cap[PT_PAIRS] || 4 * (size_t)(nx + 1) > M.cap[PT_OINFO])
+        M.full_upload = true;
+      mirror_add_edge (M, s, c, nx);
+      if (s == 0)
+        mirror_refresh_root_child (M, nx); /* a new child of the root: its root-table entry */
+      else if (M.parent[s] == 0 && s != 0) {
+        /* s is a child of the root and got another edge: c is now a second symbol, and the
+         * child's pair / ALWAYS flag may have changed */
+        if (c < M.tab[PT_LUT].size ())
+          M.set (PT_LUT, c, M.tab[PT_LUT][c] | ST_SECOND);
+        mirror_refresh_root_child (M, s);
+      }
+    }
+    s = nx;
+  }
+  /* terminal: what a record of this keyword carries (length, keyword id) */
+  M.set (PT_REC, 8 * (size_t)s + 3, 1);
+  M.set (PT_OINFO, 4 * (size_t)s + 0, 1);
+  M.set (PT_OINFO, 4 * (size_t)s + 2, len);
+  M.set (PT_OINFO, 4 * (size_t)s + 3, kw);
+  if (M.parent[s] == 0 && s != 0)
+    mirror_refresh_root_child (M, s);
+  if (len > M.lmax)
+    M.lmax = len;
+  M.n_keywords++;
+}
+
 /* maps n symbols of d_text to class ids into the plan's own buffer (grown as needed) */
 int
-classmap_text (ACMPlan *p, const void *d_text, uint64_t n, hipStream_t st) {
-  const uint32_t sb = p->finfo.sym_bytes;
-  const size_t bytes = (size_t)n * sb;
+ensure_remap_buffer (ACMPlan *p, size_t bytes, hipStream_t st) {
   if (p->remap_bytes < bytes + 16) {
     if (p->d_remap) {
       HIP_TRY (hipStreamSynchronize (st)); /* an earlier scan may still read the old buffer */
@@ -2261,6 +2578,16 @@ classmap_text (ACMPlan *p, const void *d_text, uint64_t n, hipStream_t st) {
       return ACM_GPU_E_NOMEM;
     p->remap_bytes = want;
   }
+  return ACM_GPU_OK;
+}
+
+int
+classmap_text (ACMPlan *p, const void *d_text, uint64_t n, hipStream_t st) {
+  const uint32_t sb = p->finfo.sym_bytes;
+  const size_t bytes = (size_t)n * sb;
+  int rc0 = ensure_remap_buffer (p, bytes, st);
+  if (rc0)
+    return rc0;
   const bool aligned = (reinterpret_cast<uintptr_t> (d_text) & 15) == 0;
   const uint64_t blocks16 = aligned ? bytes / 16 : 0;
   if (blocks16) {
@@ -2298,11 +2625,24 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     HIP_TRY (hipMemsetAsync (d_count, 0, sizeof (uint64_t), st));
   if (n == 0 || p->finfo.n_edges == 0 || emit_from >= n)
     return ACM_GPU_OK;
+  if (p->mir && (p->mir->full_upload || !p->mir->patches.empty ())) {
+    int rc = starts_flush (p, st); /* dictionary updates since the last scan */
+    if (rc)
+      return rc;
+  }
   if (p->d_classlut) {
     /* comparator-class plan: walk the class ids of the text (our own, aligned, copy) */
     int rc = classmap_text (p, d_text, n, st);
     if (rc)
       return rc;
+    d_text = p->d_remap;
+  } else if (p->starts && (reinterpret_cast<uintptr_t> (d_text) & 15) != 0) {
+    /* start-parallel plan, buffer not 16-byte aligned: scan an aligned copy (the CSR walk that
+     * would take it as it is runs 20x slower, and knows nothing of incremental updates) */
+    int rc = ensure_remap_buffer (p, (size_t)n * sb, st);
+    if (rc)
+      return rc;
+    HIP_TRY (hipMemcpyAsync (p->d_remap, d_text, (size_t)n * sb, hipMemcpyDeviceToDevice, st));
     d_text = p->d_remap;
   }
   if (use_dense) {
@@ -2652,6 +2992,78 @@ acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint64_t
 #undef HOST_TRY
 }
 
+/* the reference's dictionaries grow while they are used (README.md:352-356,
+ * generic_test.c:214-229).  Brings `plan` up to date with `machine` (the machine it was made from,
+ * later): plans of the start-parallel kernel take the new keywords as edits of a few table words
+ * (StartsMirror); the other kernels' tables are functions of the whole dictionary (a new keyword
+ * changes a column of up to every failure-resolved row), so they are rebuilt -- 0.5 ms at 1,000
+ * keywords -- behind the same handle. */
+extern "C" int
+acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
+  if (!plan || !machine)
+    return ACM_GPU_E_ARG;
+  const uint64_t gen = acm_internal_generation (machine);
+  uint32_t sym_bytes = 0;
+  const bool plain = acm_internal_symbol_bytes (machine, &sym_bytes) == ACM_GPU_OK;
+  if (plan->mir && plan->starts && plain && !plan->d_classlut && sym_bytes == plan->finfo.sym_bytes) {
+    StartsMirror &M = *plan->mir;
+    acm_internal_lock (machine);
+    const uint32_t nk = (uint32_t)acm_nb_keywords (machine);
+    if (nk < M.n_keywords) {
+      acm_internal_unlock (machine);
+      return ACM_GPU_E_ARG; /* not the machine this plan came from */
+    }
+    MatchHolder h;
+    acm_matcher_init (&h);
+    std::vector<uint32_t> sym;
+    int rc = ACM_GPU_OK;
+    for (uint32_t k = M.n_keywords; k < nk && rc == ACM_GPU_OK; k++) {
+      rc = acm_get_keyword (machine, k, &h);
+      if (rc)
+        break;
+      sym.resize (h.length);
+      for (size_t i = 0; i < h.length; i++) {
+        const unsigned char *l = static_cast<const unsigned char *> (h.letters[i]);
+        uint32_t v = 0;
+        for (uint32_t bb = 0; bb < sym_bytes; bb++)
+          v |= (uint32_t)l[bb] << (8 * bb);
+        sym[i] = v;
+      }
+      if (M.n_states + h.length >= ST_STATE)
+        rc = ACM_GPU_E_INELIGIBLE;
+      else
+        mirror_insert (M, sym.data (), (uint32_t)h.length, k);
+    }
+    acm_matcher_release (&h);
+    acm_internal_unlock (machine);
+    if (rc)
+      return rc;
+    plan->finfo.n_states = M.n_states;
+    plan->finfo.n_edges = M.n_edges;
+    plan->finfo.n_keywords = M.n_keywords;
+    plan->finfo.lmax = M.lmax;
+    plan->generation = gen;
+    return ACM_GPU_OK;
+  }
+  /* rebuild behind the same handle */
+  ACMPlan *fresh = nullptr;
+  int rc = plan->d_classlut ? acm_gpu_plan_create_classes (machine, plan->class_sym_bytes, plan->device, &fresh)
+                            : acm_gpu_plan_create (machine, plan->device, &fresh);
+  if (rc)
+    return rc;
+  HIP_TRY (hipSetDevice (plan->device));
+  HIP_TRY (hipDeviceSynchronize ()); /* scans in flight still read the old tables */
+  const bool timing = plan->timing;
+  const uint64_t segment = plan->segment;
+  std::swap (*plan, *fresh);
+  acm_gpu_plan_destroy (fresh);
+  plan->segment = segment;
+  plan->generation = gen;
+  if (timing)
+    (void)acm_gpu_plan_timing (plan, 1);
+  return ACM_GPU_OK;
+}
+
 extern "C" int
 acm_scan (ACMachine *machine, const void *text, uint64_t n_symbols, ACMRecord *records, uint64_t capacity, uint64_t *n_found) {
   if (!machine || !n_found)
@@ -2660,11 +3072,12 @@ acm_scan (ACMachine *machine, const void *text, uint64_t n_symbols, ACMRecord *r
   void **slot = acm_internal_plan_slot (machine);
   ACMPlan *plan = static_cast<ACMPlan *> (*slot);
   const uint64_t gen = acm_internal_generation (machine);
-  if (!plan || plan->generation != gen) {
-    if (plan) {
-      acm_gpu_plan_destroy (plan);
-      *slot = nullptr;
-    }
+  if (plan && plan->generation != gen) {
+    int rc = acm_gpu_plan_update (plan, machine);
+    if (rc)
+      return rc;
+  }
+  if (!plan) {
     int device = 0;
     if (const char *e = getenv ("ACM_GPU_DEVICE"))
       device = atoi (e);

@@ -159,6 +159,13 @@ int acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out);
  * 1- or 2-byte symbols.  Scans of such a plan first map the text to class ids (one more pass over
  * the text into a buffer the plan owns), then run the same kernels. */
 int acm_gpu_plan_create_classes (ACMachine *machine, uint32_t sym_bytes, int device, ACMPlan **out);
+/* Brings a plan up to date with the machine it was made from after keywords were added to it
+ * (the reference inserts while it scans: README.md:352-356, generic_test.c:214-229).  Plans of
+ * the start-parallel kernel (2- and 4-byte symbols) are edited in place: only the words of the new
+ * keywords' own states change, and they are written on the stream of the next scan, in front of
+ * it.  Plans of the other kernels are rebuilt behind the same handle.  Not while a stream
+ * (acm_gpu_stream_*) is open on the plan.  acm_scan() calls this by itself. */
+int acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine);
 void acm_gpu_plan_destroy (ACMPlan *plan);
 void acm_gpu_plan_info (const ACMPlan *plan, ACMPlanInfo *info);
 

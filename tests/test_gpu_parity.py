@@ -465,3 +465,75 @@ def test_interleaved_classes_and_u16_on_the_gpu(torch_cuda, kat):
     assert want16.size >= 999 * 8
     assert np.array_equal(plan16.scan_sorted(_dev(torch_cuda, text16)), want16)
     assert np.array_equal(plan16.scan_sorted(_dev(torch_cuda, text16)[1:]), o16.scan(text16[1:]))
+
+
+def test_incremental_updates_of_a_start_parallel_plan(torch_cuda):
+    """keywords added while the plan is in use (reference README.md:352-356,
+    generic_test.c:214-229).  uint32 symbols: the plan is edited in place (a few table words per
+    keyword, written in front of the next scan); after every batch the records equal the oracle's."""
+    rng = np.random.default_rng(11)
+    V = 5000
+    def word(lo, hi):
+        return rng.integers(0, V, size=rng.integers(lo, hi)).astype(np.uint32)
+    base = [word(2, 6) for _ in range(400)]
+    m, o = build_pair(base, 4)
+    text = rng.integers(0, V, size=200000).astype(np.uint32)
+    # plant occurrences of keywords that exist now and of some that come later
+    later = [word(1, 7) for _ in range(300)]
+    later += [np.concatenate([base[i], word(1, 3)]) for i in range(40)]            # extensions of keywords
+    later += [base[i][:max(1, base[i].size - 1)] for i in range(40, 80)]            # prefixes: inner states turn terminal
+    later += [np.array([V + 7, 3, 4], np.uint32), np.array([V + 7], np.uint32), np.array([12, V + 900], np.uint32)]  # symbols beyond the root table
+    later += [np.array([base[0][0]], np.uint32)]                                    # a single symbol that is already a root child
+    for i, kw in enumerate(base[:200] + later):
+        at = int(rng.integers(0, text.size - 16))
+        text[at:at + kw.size] = kw
+    dev = _dev(torch_cuda, text)
+    plan = m.plan(0)
+    assert plan.info.kernel == 4
+    assert np.array_equal(plan.scan_sorted(dev), o.scan(text))
+    order = rng.permutation(len(later))
+    step = 0
+    for lo in range(0, len(later), 37):
+        for j in order[lo:lo + 37]:
+            m.add_keyword(later[j])
+            o.add_keyword(later[j])
+        plan.update(m)
+        want = o.scan(text)
+        got = plan.scan_sorted(dev)
+        assert got.size == want.size and np.array_equal(got, want), "after batch %d" % step
+        if step % 3 == 0:
+            assert int(plan.count(dev).item()) == want.size
+            assert np.array_equal(plan.scan_sorted(dev[1:]), o.scan(text[1:]))      # unaligned buffer: aligned copy inside
+        step += 1
+    # the edited plan equals one built from scratch
+    assert np.array_equal(m.plan(0).scan_sorted(dev), plan.scan_sorted(dev))
+    # one keyword at a time through acm_scan (machine-cached plan)
+    for kw in [word(2, 5) for _ in range(25)]:
+        m.add_keyword(kw)
+        o.add_keyword(kw)
+        assert np.array_equal(m.scan_host(text[:50000]), o.scan(text[:50000]))
+
+
+def test_plan_update_rebuilds_dense_and_class_plans(torch_cuda, kat):
+    m, o = build_pair([b"he", b"she"], 1)
+    text = b"ushers and heroes; she sells hers and HIS " * 300
+    plan = m.plan(0)
+    dev = _dev(torch_cuda, text)
+    assert np.array_equal(plan.scan_sorted(dev), o.scan(text))
+    for w in (b"his", b"hers", b"s", b"sells hers"):
+        m.add_keyword(w)
+        o.add_keyword(w)
+        plan.update(m)
+        assert np.array_equal(plan.scan_sorted(dev), o.scan(text))
+    mc = acm.Machine(1, cmp=_fn_ptr(kat, "kat_casecmp8"))
+    oc = po.Oracle(1, po.MEYER85, cmp=_fn_ptr(kat, "kat_casecmp8"))
+    for w in (b"He", b"she"):
+        mc.add_keyword(w)
+        oc.add_keyword(w)
+    pc = mc.plan_classes(0)
+    assert np.array_equal(pc.scan_sorted(dev), oc.scan(text))
+    for w in (b"HIS", b"hErs"):
+        mc.add_keyword(w)
+        oc.add_keyword(w)
+    pc.update(mc)
+    assert np.array_equal(pc.scan_sorted(dev), oc.scan(text))
