@@ -1108,10 +1108,34 @@ struct StartsK {
 constexpr uint32_t ST_ALWAYS = 0x80000000u, ST_SECOND = 0x40000000u, ST_STATE = 0x3FFFFFFFu;
 
 /* Matches found by a wave collect in its LDS hit buffer as (end position, terminal state) and
- * leave 64 at a time: one atomic on the record counter per 64 records (one per find was 0.7 ms of
- * serialised atomics on config 5: a single address sustains ~90 per microsecond). */
+ * leave up to 64 at a time for the wave's private region of the plan's item buffer in HBM (plain
+ * coalesced stores); expand_hits_kernel turns the regions into records afterwards with one atomic
+ * per block.  (One atomic on the record counter per find was 0.7 ms of serialised atomics on
+ * config 5, one per 64 finds still 6 ms on config 3's 27 M matches: a single address sustains
+ * ~90 atomics per microsecond.)  A full region falls back to records straight from here.
+ * LDS per wave: [region pointer][capacity, fill][64 hits]. */
+constexpr uint32_t HITS_STRIDE = WAVE + 2; /* in 8-byte units */
+
 __device__ __forceinline__ void
-flush_hits (const EmitCtx &E, const uint2 *hits, uint32_t n, uint32_t lane) {
+hits_init (uint2 *hits, uint2 *region, uint32_t capacity, uint32_t lane) {
+  if (lane == 0) {
+    const uint64_t a = reinterpret_cast<uint64_t> (region);
+    hits[-2] = make_uint2 ((uint32_t)a, (uint32_t)(a >> 32));
+    hits[-1] = make_uint2 (region ? capacity : 0u, 0u);
+  }
+}
+
+__device__ __forceinline__ void
+flush_hits (const EmitCtx &E, uint2 *hits, uint32_t n, uint32_t lane) {
+  const uint2 rp = hits[-2], cf = hits[-1];
+  if (cf.y + n <= cf.x) {
+    uint2 *region = reinterpret_cast<uint2 *> (((uint64_t)rp.y << 32) | rp.x);
+    if (lane < n)
+      region[cf.y + lane] = hits[lane];
+    if (lane == 0)
+      hits[-1] = make_uint2 (cf.x, cf.y + n);
+    return;
+  }
   unsigned long long base = 0;
   if (lane == 0)
     base = atomicAdd (E.count, (unsigned long long)n);
@@ -1121,6 +1145,49 @@ flush_hits (const EmitCtx &E, const uint2 *hits, uint32_t n, uint32_t lane) {
     const uint4 oi = E.oinfo[h.y]; /* terminal state: its first output is its own keyword */
     const uint64_t gp = E.pos_base + h.x;
     *reinterpret_cast<uint4 *> (&E.records[base + lane]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), oi.z, oi.w);
+  }
+}
+
+/* one record per parked hit; a block takes REGIONS consecutive regions and reserves their
+ * records with one atomic; it zeroes the fill counters it consumed */
+template <int THREADS, int REGIONS>
+__global__ __launch_bounds__ (THREADS) void
+expand_hits_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint32_t *fill, uint32_t n_regions) {
+  __shared__ uint32_t s_off[REGIONS + 1];
+  __shared__ unsigned long long s_base;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t r0 = blockIdx.x * REGIONS;
+  if (tid < REGIONS) {
+    const uint32_t r = r0 + tid;
+    s_off[tid + 1] = r < n_regions ? fill[r] : 0;
+    if (r < n_regions)
+      fill[r] = 0;
+  }
+  __syncthreads ();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (int r = 0; r < REGIONS; r++) {
+      const uint32_t v = s_off[r + 1];
+      s_off[r] = acc;
+      acc += v;
+    }
+    s_off[REGIONS] = acc;
+    s_base = acc ? atomicAdd (E.count, (unsigned long long)acc) : 0ull;
+  }
+  __syncthreads ();
+  const uint32_t total = s_off[REGIONS];
+  const unsigned long long base = s_base;
+  for (uint32_t i = tid; i < total; i += THREADS) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 1; k < REGIONS; k++)
+      r += s_off[k] <= i ? 1u : 0u;
+    const uint2 h = items[(size_t)(r0 + r) * region_items + (i - s_off[r])];
+    if (base + i < E.capacity) {
+      const uint4 oi = E.oinfo[h.y];
+      const uint64_t gp = E.pos_base + h.x;
+      *reinterpret_cast<uint4 *> (&E.records[base + i]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), oi.z, oi.w);
+    }
   }
 }
 
@@ -1241,7 +1308,8 @@ struct PendingStart {
 
 template <typename SYM, bool LUT_LDS, bool COUNT_ONLY>
 __global__ __launch_bounds__ (SPARSE_THREADS) void
-scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text8) {
+scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text8, uint2 *items, uint32_t region_items,
+                    uint32_t *fill) {
   extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
   constexpr uint32_t PER = 16 / sizeof (SYM);  /* symbols per lane per group */
   constexpr uint32_t PERW = 4 / sizeof (SYM);  /* symbols per 32-bit word */
@@ -1254,7 +1322,7 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
       dst[i] = src[i];
   }
   constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
-  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (QCAP + WAVE) * 8);
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (QCAP + HITS_STRIDE) * 8);
   if (threadIdx.x == 0)
     *next_tile = 0;
   __syncthreads ();
@@ -1262,7 +1330,9 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint32_t wib = uniform (threadIdx.x / WAVE);
   uint2 *queue = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
-  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * WAVE;
+  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * HITS_STRIDE + 2;
+  const uint32_t wave_id = blockIdx.x * WAVES + wib;
+  hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
   const SYM *text = reinterpret_cast<const SYM *> (text8);
   const uint4 *text16 = reinterpret_cast<const uint4 *> (text8);
   const uint32_t ntiles = A.range_end - A.range_begin;
@@ -1392,8 +1462,12 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
     const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
     if (lane == 0 && total)
       atomicAdd (E.count, (unsigned long long)total);
-  } else if (counted)
-    flush_hits (E, hits, (uint32_t)counted, lane);
+  } else {
+    if (counted)
+      flush_hits (E, hits, (uint32_t)counted, lane);
+    if (lane == 0 && fill)
+      fill[wave_id] = hits[-1].y;
+  }
   DIAG (if (lane == 0) {
     const uint32_t wave = blockIdx.x * (SPARSE_THREADS / WAVE) + wib;
     if (wave < 8192) {
@@ -1406,6 +1480,190 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
       o[5] = d_tiles;
     }
   })
+}
+
+/* ------------------------------------------------------------------ 4-gram sieve kernel (byte alphabets, big dictionaries)
+ * Dictionaries whose automaton does not fit the LDS scheme of the dense kernel (more than 32,768
+ * states: config 3 has 508,339) make every step of a carried-state walk a dependent gather into
+ * tens of megabytes of rows (99 GB/s).  When every keyword has at least 4 symbols and the
+ * alphabet is small (width W = span + 1 <= 30), the start-parallel idea works for bytes too:
+ *   1. LDS holds one bit per possible 4-gram over the W classes (W^4 bits: 66 KB for a-z): "some
+ *      keyword starts with it".  Every position is tested with one ds_read_b32 on a rolling
+ *      4-gram index (config 3: 19.6% pass);
+ *   2. the survivors are queued per wave as (position, 4-gram index, class of the 5th symbol)
+ *      and checked 64 at a time against an 8-byte record per 4-gram: {terminal bit | 26-bit mask
+ *      of the depth-4 state's children, its state id}; the gather of batch k is in flight
+ *      while the scan fills batch k + 1 (config 3: 3.2% of the positions pass -- all real:
+ *      a keyword of length 4 ends there or a 5-symbol prefix of a keyword does);
+ *   3. those go to walk_starts (shared with the start-parallel kernel) at the depth-4 state.
+ * Text is read as in the start-parallel kernel (1 KiB groups, 16 bytes per lane, four groups in
+ * flight). */
+struct GramK {
+  const uint2 *g4rec;     /* [W^4] {children mask | terminal << 31, state id of the depth-4 node (0: none)} */
+  const uint32_t *g4bits; /* [g4words] one bit per 4-gram, staged in LDS */
+  const uint4 *srec;      /* trie records as in StartsK (edge symbols are raw bytes) */
+  const uint2 *sedge;
+  uint32_t g4words;
+  uint32_t W, lo, span, W4; /* class = min (byte - lo, span); W = span + 1 */
+  uint32_t R;             /* groups per tile */
+  uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
+};
+
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__ (SPARSE_THREADS) void
+scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
+                  uint32_t *fill) {
+  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
+  constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
+  constexpr uint32_t GROUP = WAVE * 16;
+  {
+    uint4 *dst = reinterpret_cast<uint4 *> (smem);
+    const uint4 *src = reinterpret_cast<const uint4 *> (K.g4bits);
+    for (uint32_t i = threadIdx.x; i < (K.g4words + 3) / 4; i += blockDim.x)
+      dst[i] = src[i];
+  }
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (2 * QCAP + HITS_STRIDE) * 8);
+  if (threadIdx.x == 0)
+    *next_tile = 0;
+  __syncthreads ();
+
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint32_t wib = uniform (threadIdx.x / WAVE);
+  uint2 *q1 = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
+  uint2 *q2 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * QCAP;
+  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + 2 * WAVES * QCAP + wib * HITS_STRIDE + 2;
+  const uint32_t wave_id = blockIdx.x * WAVES + wib;
+  hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
+  const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
+  const uint32_t ntiles = A.range_end - A.range_begin;
+  const uint32_t tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
+  const uint32_t blk_begin = blockIdx.x * tiles_per_block;
+  const uint32_t blk_tiles = blk_begin >= ntiles ? 0 : (ntiles - blk_begin < tiles_per_block ? ntiles - blk_begin : tiles_per_block);
+  const uint32_t last_blk = (A.n - 1) / 16;
+  uint32_t qn1 = 0, qn2 = 0;
+  unsigned long long counted = 0;
+  /* batch of the first queue whose records are in flight */
+  uint2 pend_item = make_uint2 (0, 0), pend_rec = make_uint2 (0, 0);
+  uint32_t pend_n = 0; /* wave-uniform: items in the pending batch */
+
+  auto load_group = [&] (uint32_t g) -> uint4 {
+    const uint32_t blk = g * WAVE + lane;
+    return text16[blk < last_blk ? blk : last_blk];
+  };
+  auto walk_batch = [&] (uint32_t n_items) {
+    StartsK Kc{};
+    Kc.srec = K.srec;
+    Kc.sedge = K.sedge;
+    const EmitCtx Ec = E;
+    counted = walk_starts<uint8_t, COUNT_ONLY> (&Kc, &Ec, text, q2 + qn2, n_items, hits, counted);
+    if (!COUNT_ONLY)
+      counted = uniform ((uint32_t)counted);
+  };
+  /* second sieve on the pending batch: terminal, or the 5th symbol is an edge of the depth-4 state */
+  auto consume_pending = [&] () {
+    if (pend_n) {
+      const uint32_t c4 = pend_item.y >> 20;
+      const bool pass = lane < pend_n && (((pend_rec.x >> 31) | (pend_rec.x >> c4)) & 1u);
+      const uint64_t m = __ballot (pass);
+      if (m) {
+        if (pass)
+          q2[qn2 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pend_item.x + 3, pend_rec.y);
+        qn2 = uniform (qn2 + (uint32_t)__popcll (m));
+        if (qn2 >= WAVE) {
+          qn2 -= WAVE;
+          walk_batch (WAVE);
+        }
+      }
+      pend_n = 0;
+    }
+  };
+  /* takes the newest n items of the first queue and sends for their records */
+  auto issue_batch = [&] (uint32_t n_items) {
+    qn1 -= n_items;
+    pend_item = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
+    pend_rec = K.g4rec[pend_item.y & 0xFFFFFu];
+    pend_n = n_items;
+  };
+
+  /* one group: cur = this lane's 16 bytes, next_x = the first 4 bytes of every lane of the next group */
+  auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t g) {
+    uint32_t after = __shfl_down (cur.x, 1, WAVE);
+    const uint32_t after_group = uniform (next_x);
+    if (lane == WAVE - 1)
+      after = after_group;
+    const uint32_t pos0 = g * GROUP + lane * 16;
+    const uint32_t w[5] = { cur.x, cur.y, cur.z, cur.w, after };
+    uint32_t c[20];
+#pragma unroll
+    for (int j = 0; j < 20; j++) {
+      const uint32_t b = (w[j / 4] >> (8 * (j % 4))) & 0xFFu;
+      c[j] = min (b - K.lo, K.span);
+    }
+    /* symbols past the end of the segment count as outside the alphabet (only the last groups) */
+    if (pos0 + 20 > A.n) {
+#pragma unroll
+      for (int j = 0; j < 20; j++)
+        if (pos0 + j >= A.n)
+          c[j] = K.span;
+    }
+    uint32_t idx = ((c[0] * K.W + c[1]) * K.W + c[2]) * K.W + c[3];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t word = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
+      const bool push = (word >> (idx & 31u)) & 1u;
+      const uint64_t m = __ballot (push);
+      if (m) {
+        if (push)
+          q1[qn1 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos0 + j, idx | (c[j + 4] << 20));
+        qn1 = uniform (qn1 + (uint32_t)__popcll (m));
+        if (qn1 >= WAVE) {
+          consume_pending ();
+          issue_batch (WAVE);
+        }
+      }
+      idx = idx * K.W + c[j + 4] - c[j] * K.W4;
+    }
+  };
+
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0)
+      t = atomicAdd (next_tile, 1u);
+    t = uniform (t);
+    if (t >= blk_tiles)
+      break;
+    const uint32_t g0 = (A.range_begin + blk_begin + t) * K.R;
+    uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
+    for (uint32_t k = 0; k < K.R; k++) {
+      const uint4 n3 = load_group (g0 + k + 4);
+      walk_group (c0, c1.x, g0 + k);
+      c0 = c1;
+      c1 = c2;
+      c2 = c3;
+      c3 = n3;
+    }
+  }
+  consume_pending ();
+  if (qn1) {
+    issue_batch (qn1);
+    consume_pending ();
+  }
+  if (qn2) {
+    const uint32_t left = qn2;
+    qn2 = 0;
+    walk_batch (left);
+  }
+  if (COUNT_ONLY) {
+    const uint32_t incl = wave_incl_scan ((uint32_t)counted);
+    const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
+    if (lane == 0 && total)
+      atomicAdd (E.count, (unsigned long long)total);
+  } else {
+    if (counted)
+      flush_hits (E, hits, (uint32_t)counted, lane);
+    if (lane == 0 && fill)
+      fill[wave_id] = hits[-1].y;
+  }
 }
 
 /* ------------------------------------------------------------------ comparator classes
@@ -1548,6 +1806,9 @@ struct ACMPlan {
   StartsK TK{};
   bool starts = false; /* start-parallel kernel instead of the sparse walk */
   StartsMirror *mir = nullptr; /* starts plans: what acm_gpu_plan_update edits */
+  GramK GK{};
+  bool gram = false; /* 4-gram sieve kernel instead of the sticky dense walk */
+  uint32_t gram_lds_bytes = 0;
   uint32_t class_sym_bytes = 0; /* comparator-class plans: the symbol size they were made for */
   bool sparse = false, sparse_lut_lds = false, starts_lut_lds = false;
   uint32_t sparse_lds_bytes = 0, starts_lds_bytes = 0;
@@ -1768,6 +2029,23 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const size_t o_tedge = blob_reserve (cur, starts ? (size_t)fi.n_edges * 8 : 0);
   const size_t o_tlut = blob_reserve (cur, starts ? (size_t)lut_size * 4 + 16 : 0);
   const size_t o_tpairs = blob_reserve (cur, starts ? (size_t)n * 8 : 0); /* by state id; filled for the root's children */
+  /* 4-gram sieve kernel: byte alphabets of width <= 30 whose automaton is too big for the LDS
+   * scheme, every keyword at least 4 symbols long */
+  bool gram = dense && entry_bytes == 4 && fi.width <= 30 && fi.width == fi.alpha_span + 1 && fi.lmax >= 4 && n < 0x7FFFFFFFu;
+  if (gram) {
+    for (uint32_t k = 0; k < fi.n_keywords && gram; k++)
+      gram = fv.depth[fv.kw_state[k]] >= 4;
+    const char *e = getenv ("ACM_GPU_GRAM");
+    if (e && atoi (e) == 0)
+      gram = false;
+  }
+  const uint32_t gW = fi.width;
+  const uint32_t gW4 = gram ? gW * gW * gW * gW : 0;
+  const uint32_t g4words = (gW4 + 31) / 32;
+  const size_t o_g4bits = blob_reserve (cur, gram ? (size_t)g4words * 4 + 16 : 0);
+  const size_t o_g4rec = blob_reserve (cur, gram ? (size_t)gW4 * 8 : 0);
+  const size_t o_grec = blob_reserve (cur, gram ? (size_t)n * 32 : 0);
+  const size_t o_gedge = blob_reserve (cur, gram ? (size_t)fi.n_edges * 8 : 0);
   p->blob_bytes = cur;
 
   std::vector<unsigned char> host (cur, 0);
@@ -1863,6 +2141,42 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       if (fv.edge_sym[e] < lut_size)
         lut[fv.edge_sym[e]] |= ST_SECOND;
   }
+  if (gram) {
+    uint32_t *bits = reinterpret_cast<uint32_t *> (&host[o_g4bits]);
+    uint32_t *g4 = reinterpret_cast<uint32_t *> (&host[o_g4rec]);
+    uint32_t *rec = reinterpret_cast<uint32_t *> (&host[o_grec]);
+    uint32_t *edge = reinterpret_cast<uint32_t *> (&host[o_gedge]);
+    for (uint32_t e = 0; e < fi.n_edges; e++) {
+      edge[2 * e] = fv.edge_sym[e];
+      edge[2 * e + 1] = fv.edge_next[e];
+    }
+    for (uint32_t st = 0; st < n; st++) {
+      const uint32_t b0 = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b0;
+      uint32_t *r = rec + 8 * (size_t)st;
+      r[1] = ne;
+      r[2] = b0;
+      r[3] = fv.term_kw[st] != NONE ? 1u : 0u;
+      r[4] = ne >= 1 ? fv.edge_sym[b0] : 0;
+      r[5] = ne >= 1 ? fv.edge_next[b0] : 0;
+      r[6] = ne >= 2 ? fv.edge_sym[b0 + 1] : 0;
+      r[7] = ne >= 2 ? fv.edge_next[b0 + 1] : 0;
+    }
+    /* base-W number of the path of every state down to depth 4 (parents come first in
+     * breadth-first order); the depth-4 states are the 4-grams some keyword starts with */
+    std::vector<uint32_t> path (fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1], 0);
+    for (uint32_t st = 0; st < fv.depth_start[4]; st++)
+      for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
+        path[fv.edge_next[e]] = path[st] * gW + (fv.edge_sym[e] - fi.alpha_lo);
+    for (uint32_t st = fv.depth_start[4]; st < fv.depth_start[5]; st++) {
+      const uint32_t idx = path[st];
+      uint32_t mask = fv.term_kw[st] != NONE ? 0x80000000u : 0u;
+      for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
+        mask |= 1u << (fv.edge_sym[e] - fi.alpha_lo);
+      bits[idx >> 5] |= 1u << (idx & 31);
+      g4[2 * (size_t)idx] = mask;
+      g4[2 * (size_t)idx + 1] = st;
+    }
+  }
   if (dense) {
     int rc = acm_flat_dense_rows (flat, n, entry_bytes, &host[o_dense]);
     if (rc) {
@@ -1928,6 +2242,25 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     K.stream_stride = WAVE * p->chunk;
   }
   p->d_dstart = u32p (o_dstart);
+  if (gram) {
+    const uint32_t lds_total = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
+    const uint32_t gq = (SPARSE_THREADS / WAVE) * (2 * QCAP + HITS_STRIDE) * 8;
+    const uint32_t bits_bytes = (g4words * 4 + 15) & ~15u;
+    if ((uint64_t)bits_bytes + gq + 16 <= lds_total) {
+      p->gram = true;
+      p->GK.g4rec = reinterpret_cast<const uint2 *> (b + o_g4rec);
+      p->GK.g4bits = u32p (o_g4bits);
+      p->GK.srec = reinterpret_cast<const uint4 *> (b + o_grec);
+      p->GK.sedge = reinterpret_cast<const uint2 *> (b + o_gedge);
+      p->GK.g4words = g4words;
+      p->GK.W = gW;
+      p->GK.lo = fi.alpha_lo;
+      p->GK.span = fi.alpha_span;
+      p->GK.W4 = gW4;
+      p->GK.queue_off = bits_bytes;
+      p->gram_lds_bytes = bits_bytes + gq + 16;
+    }
+  }
   if (sparse) {
     const uint32_t tps = 128 / fi.sym_bytes;
     const uint32_t warm = fi.lmax > 1 ? fi.lmax - 1 : 0;
@@ -1952,7 +2285,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       p->TK.lut = u32p (o_tlut);
       p->TK.pairs = reinterpret_cast<const uint2 *> (b + o_tpairs);
       p->TK.lut_size = lut_size;
-      const uint32_t starts_queue_bytes = (SPARSE_THREADS / WAVE) * (QCAP + WAVE) * 8;
+      const uint32_t starts_queue_bytes = (SPARSE_THREADS / WAVE) * (QCAP + HITS_STRIDE) * 8;
       p->starts_lut_lds = (uint64_t)lut_size * 4 + starts_queue_bytes + 16 <= lds_total;
       p->TK.queue_off = p->starts_lut_lds ? lut_size * 4 : 0;
       p->TK.R = 0;
@@ -1997,7 +2330,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
 
   ACMPlanInfo &I = p->info;
   I.device = device;
-  I.kernel = dense ? 1 : (sparse ? (p->starts ? 4 : 3) : 2);
+  I.kernel = p->gram ? 5 : (dense ? 1 : (sparse ? (p->starts ? 4 : 3) : 2));
   I.entry_bytes = dense ? entry_bytes : 0;
   I.width = fi.width;
   I.dense_rows = dense ? n : 0;
@@ -2023,6 +2356,12 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
         HIP_TRY (hipFuncSetAttribute (starts_kernel_ptr (fi.sym_bytes, p->starts_lut_lds, co != 0),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->starts_lds_bytes));
     }
+  }
+  if (p->gram) {
+    HIP_TRY (hipFuncSetAttribute (reinterpret_cast<const void *> (&scan_gram_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->gram_lds_bytes));
+    HIP_TRY (hipFuncSetAttribute (reinterpret_cast<const void *> (&scan_gram_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->gram_lds_bytes));
   }
   if (dense) {
     for (int co = 0; co < 2; co++)
@@ -2208,6 +2547,13 @@ launch_sparse (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
   return ACM_GPU_OK;
 }
 
+/* records of the hits parked by `regions_used` waves of the start-parallel / 4-gram kernels */
+void
+launch_expand_hits (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, hipStream_t st) {
+  hipLaunchKernelGGL ((expand_hits_kernel<1024, 8>), dim3 ((regions_used + 7) / 8), dim3 (1024), 0, st, E,
+                      static_cast<const uint2 *> (p->d_items), p->region_items, p->d_fill, regions_used);
+}
+
 template <bool COUNT_ONLY>
 int
 launch_starts (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
@@ -2231,9 +2577,44 @@ launch_starts (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
   const uint32_t tiles = a.range_end - a.range_begin;
   if ((tiles + wpb - 1) / wpb < grid)
     grid = (tiles + wpb - 1) / wpb;
-  void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text };
+  void *items = COUNT_ONLY ? nullptr : p->d_items;
+  uint32_t *fill = COUNT_ONLY ? nullptr : p->d_fill;
+  void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
   HIP_TRY (hipLaunchKernel (starts_kernel_ptr (p->finfo.sym_bytes, p->starts_lut_lds, COUNT_ONLY), dim3 (grid),
                             dim3 (SPARSE_THREADS), args, p->starts_lds_bytes, st));
+  if (!COUNT_ONLY)
+    launch_expand_hits (p, E, grid * wpb, st);
+  return ACM_GPU_OK;
+}
+
+template <bool COUNT_ONLY>
+int
+launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
+  const uint32_t group = WAVE * 16;
+  const uint32_t ngroups = (uint32_t)(((uint64_t)a.n + group - 1) / group);
+  uint32_t grid = (uint32_t)p->cu_count;
+  const uint32_t wpb = SPARSE_THREADS / WAVE;
+  const uint32_t back = p->finfo.lmax > 1 ? p->finfo.lmax - 1 : 0;
+  const uint32_t first_group = (a.emit_from > back ? a.emit_from - back : 0) / group;
+  uint64_t R = (ngroups - first_group) / ((uint64_t)grid * wpb * 16);
+  if (R < 4)
+    R = 4;
+  if (R > 64)
+    R = 64;
+  GramK K = p->GK;
+  K.R = (uint32_t)R;
+  a.range_begin = first_group / (uint32_t)R;
+  a.range_end = (uint32_t)((ngroups + R - 1) / R);
+  const uint32_t tiles = a.range_end - a.range_begin;
+  if ((tiles + wpb - 1) / wpb < grid)
+    grid = (tiles + wpb - 1) / wpb;
+  void *items = COUNT_ONLY ? nullptr : p->d_items;
+  uint32_t *fill = COUNT_ONLY ? nullptr : p->d_fill;
+  void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
+  HIP_TRY (hipLaunchKernel (reinterpret_cast<const void *> (&scan_gram_kernel<COUNT_ONLY>), dim3 (grid), dim3 (SPARSE_THREADS), args,
+                            p->gram_lds_bytes, st));
+  if (!COUNT_ONLY)
+    launch_expand_hits (p, E, grid * wpb, st);
   return ACM_GPU_OK;
 }
 
@@ -2269,9 +2650,9 @@ launch_csr (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
 /* (re)allocate the item buffer for segments of up to n symbols: room for one item per 256
  * symbols, at least 256 per wave; denser matches are expanded in the kernel itself */
 int
-ensure_item_buffer (ACMPlan *p, uint64_t n) {
+ensure_item_buffer (ACMPlan *p, uint64_t n, uint32_t symbols_per_item = 256) {
   const uint32_t regions = p->info.grid_blocks * (DENSE_THREADS / WAVE);
-  uint64_t per = (n / 256 + regions - 1) / regions;
+  uint64_t per = (n / symbols_per_item + regions - 1) / regions;
   per = (per + 63) / 64 * 64;
   if (per < 256)
     per = 256;
@@ -2636,8 +3017,8 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     if (rc)
       return rc;
     d_text = p->d_remap;
-  } else if (p->starts && (reinterpret_cast<uintptr_t> (d_text) & 15) != 0) {
-    /* start-parallel plan, buffer not 16-byte aligned: scan an aligned copy (the CSR walk that
+  } else if ((p->starts || p->gram) && (reinterpret_cast<uintptr_t> (d_text) & 15) != 0) {
+    /* start-parallel / 4-gram plan, buffer not 16-byte aligned: scan an aligned copy (the CSR walk that
      * would take it as it is runs 20x slower, and knows nothing of incremental updates) */
     int rc = ensure_remap_buffer (p, (size_t)n * sb, st);
     if (rc)
@@ -2645,8 +3026,9 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     HIP_TRY (hipMemcpyAsync (p->d_remap, d_text, (size_t)n * sb, hipMemcpyDeviceToDevice, st));
     d_text = p->d_remap;
   }
-  if (use_dense) {
-    int rc = ensure_item_buffer (p, n < p->segment ? n : p->segment);
+  if (use_dense || (!COUNT_ONLY && (p->gram || p->starts))) {
+    /* 4-gram plans see dense matches (config 3: one per 38 symbols): room for one hit per 16 */
+    int rc = ensure_item_buffer (p, n < p->segment ? n : p->segment, p->gram ? 16 : 256);
     if (rc)
       return rc;
   }
@@ -2690,7 +3072,9 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     else {
       a.range_begin = 0;
       a.range_end = a.n;
-      if (p->starts && (reinterpret_cast<uintptr_t> (a.text) & 15) == 0)
+      if (p->gram)
+        rc = launch_gram<COUNT_ONLY> (p, E, a, st);
+      else if (p->starts && (reinterpret_cast<uintptr_t> (a.text) & 15) == 0)
         rc = launch_starts<COUNT_ONLY> (p, E, a, st);
       else if (p->sparse && (reinterpret_cast<uintptr_t> (a.text) & 15) == 0)
         rc = launch_sparse<COUNT_ONLY> (p, E, a, st);

@@ -144,13 +144,17 @@ def test_dense_matches_everywhere(torch_cuda):
     assert np.array_equal(m.plan(0).scan_sorted(_dev(torch_cuda, text)), o.scan(text))
 
 
-def test_rows_colder_than_lds(torch_cuda):
-    """A dictionary whose rows do not all fit in LDS: transitions through HBM-resident rows."""
+@pytest.mark.parametrize("mode", ["sticky", "gram"])
+def test_rows_colder_than_lds(torch_cuda, monkeypatch, mode):
+    """A dictionary whose rows do not all fit in LDS: transitions through HBM-resident rows (sticky
+    dense walk), or the 4-gram sieve kernel that such dictionaries get by default."""
+    if mode == "sticky":
+        monkeypatch.setenv("ACM_GPU_GRAM", "0")
     rng = np.random.default_rng(9)
     kws = [bytes(rng.integers(97, 123, size=int(rng.integers(4, 13)), dtype=np.uint8)) for _ in range(6000)]
     m, o = build_pair(kws, 1)
     plan = m.plan(0)
-    assert plan.info.kernel == 1 and plan.info.lds_rows < plan.info.dense_rows
+    assert plan.info.kernel == (1 if mode == "sticky" else 5) and plan.info.lds_rows < plan.info.dense_rows
     text = rng.integers(97, 123, size=1 << 20, dtype=np.uint8)
     for p in range(100, text.size - 16, 997):          # make deep states common
         w = kws[int(rng.integers(0, len(kws)))]
@@ -224,13 +228,18 @@ def test_u32_config5_shape(torch_cuda, monkeypatch, mode):
         assert np.array_equal(got, want[(want["end_pos"] >= b) & (want["end_pos"] < e)])
 
 
-def test_100k_dictionary_config3_shape(torch_cuda):
-    """BASELINE config 3's dictionary (100k keywords, 508,339 states) on 16 MiB of its text."""
+@pytest.mark.parametrize("mode", ["gram", "sticky"])
+def test_100k_dictionary_config3_shape(torch_cuda, monkeypatch, mode):
+    """BASELINE config 3's dictionary (100k keywords, 508,339 states) on 16 MiB of its text, with
+    the 4-gram sieve kernel and with the sticky dense walk."""
+    if mode == "sticky":
+        monkeypatch.setenv("ACM_GPU_GRAM", "0")
     kd, ko = acm.synth.keywords(100000)
     m, o = build_pair_packed(kd, ko, variant=po.MEYER85)
     n = 1 << 24
     text = acm.synth.text(n, kd, ko)
     plan = m.plan(0)
+    assert plan.info.kernel == (5 if mode == "gram" else 1)
     got = plan.scan_sorted(_dev(torch_cuda, text))
     cnt, dig = o.scan_mt(text, 8)
     assert got.size == cnt and po.digest(got) == dig
@@ -537,3 +546,25 @@ def test_plan_update_rebuilds_dense_and_class_plans(torch_cuda, kat):
         oc.add_keyword(w)
     pc.update(mc)
     assert np.array_equal(pc.scan_sorted(dev), oc.scan(text))
+
+
+def test_gram_kernel_small_alphabet_dense_matches(torch_cuda):
+    """4-gram sieve kernel on a dictionary built to stress it: 6-letter alphabet (almost every
+    4-gram is a keyword prefix), 20k keywords of 4..9 symbols, text with symbols outside the
+    alphabet, matches everywhere; shards, odd lengths and unaligned buffers included."""
+    rng = np.random.default_rng(21)
+    kws = [bytes(rng.integers(ord("a"), ord("g"), size=rng.integers(4, 10)).astype(np.uint8)) for _ in range(20000)]
+    m, o = build_pair(kws, 1)
+    text = rng.integers(ord("a") - 1, ord("h"), size=300007).astype(np.uint8)
+    plan = m.plan(0)
+    assert plan.info.kernel == 5
+    want = o.scan(text)
+    assert want.size > 50000
+    dev = _dev(torch_cuda, text)
+    got = plan.scan_sorted(dev)
+    assert got.size == want.size and np.array_equal(got, want)
+    assert int(plan.count(dev).item()) == want.size
+    for b, e in ((0, 3), (0, 4), (1, 9), (5, 4099), (1000, 200001), (text.size - 5, text.size)):
+        rb = max(b - (m.lmax - 1), 0)
+        got = plan.scan_sorted(dev[rb:e], emit_from=b - rb, pos_base=rb)
+        assert np.array_equal(got, want[(want["end_pos"] >= b) & (want["end_pos"] < e)]), (b, e)
