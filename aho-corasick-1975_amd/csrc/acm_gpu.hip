@@ -1228,12 +1228,14 @@ walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, const uint2 
   const uint32_t lane = lane_id ();
   bool alive = lane < n_items;
   const uint2 it = alive ? items[lane] : make_uint2 (0, 0);
-  uint32_t p = it.x, st = it.y;
+  uint32_t p = it.x, st = it.y & 0x7FFFFFFFu;
+  bool reported = (it.y >> 31) != 0; /* the caller has already reported what ends in the first state */
   uint4 ra = K.srec[2 * st], rb = K.srec[2 * st + 1];
   bool more = alive && p + 1 < E.n;
   uint32_t c1 = more ? (uint32_t)text[p + 1] : 0u;
   for (;;) {
-    emit_terminals<COUNT_ONLY> (E, alive && ra.w != 0 && p >= E.emit_from, p, st, lane, hits, counted);
+    emit_terminals<COUNT_ONLY> (E, alive && !reported && ra.w != 0 && p >= E.emit_from, p, st, lane, hits, counted);
+    reported = false;
     uint32_t nx = NONE;
     if (alive && more) {
       const uint32_t ne = ra.y;
@@ -1542,9 +1544,18 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   const uint32_t last_blk = (A.n - 1) / 16;
   uint32_t qn1 = 0, qn2 = 0;
   unsigned long long counted = 0;
-  /* batch of the first queue whose records are in flight */
-  uint2 pend_item = make_uint2 (0, 0), pend_rec = make_uint2 (0, 0);
-  uint32_t pend_n = 0; /* wave-uniform: items in the pending batch */
+  /* batches of the first queue whose records are in flight: a pipeline of GRAM_DEPTH batches
+   * (the gather of a batch has the time it takes the scan to fill that many more before it is
+   * looked at: one batch ahead left the L2 / MALL latency exposed) */
+  constexpr int GRAM_DEPTH = 3;
+  uint2 pend_item[GRAM_DEPTH], pend_rec[GRAM_DEPTH];
+  uint32_t pend_n[GRAM_DEPTH]; /* wave-uniform: items in each pending batch, [0] the oldest */
+#pragma unroll
+  for (int d = 0; d < GRAM_DEPTH; d++) {
+    pend_item[d] = make_uint2 (0, 0);
+    pend_rec[d] = make_uint2 (0, 0);
+    pend_n[d] = 0;
+  }
 
   auto load_group = [&] (uint32_t g) -> uint4 {
     const uint32_t blk = g * WAVE + lane;
@@ -1559,30 +1570,45 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     if (!COUNT_ONLY)
       counted = uniform ((uint32_t)counted);
   };
-  /* second sieve on the pending batch: terminal, or the 5th symbol is an edge of the depth-4 state */
-  auto consume_pending = [&] () {
-    if (pend_n) {
-      const uint32_t c4 = pend_item.y >> 20;
-      const bool pass = lane < pend_n && (((pend_rec.x >> 31) | (pend_rec.x >> c4)) & 1u);
+  /* second sieve on the oldest pending batch: terminal, or the 5th symbol is an edge of the
+   * depth-4 state; then the pipeline moves up */
+  auto consume_oldest = [&] () {
+    if (pend_n[0]) {
+      const uint32_t c4 = pend_item[0].y >> 20;
+      const bool valid = lane < pend_n[0];
+      /* a keyword of length 4 ends here: reported at once, its record needs nothing but the
+       * state id (the trie records of the 508,339 states are 16 MB of HBM: not worth a visit) */
+      const bool term = valid && (pend_rec[0].x >> 31) && pend_item[0].x + 3 >= E.emit_from;
+      emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, pend_rec[0].y, lane, hits, counted);
+      if (!COUNT_ONLY)
+        counted = uniform ((uint32_t)counted);
+      const bool pass = valid && ((pend_rec[0].x >> c4) & 1u);
       const uint64_t m = __ballot (pass);
       if (m) {
         if (pass)
-          q2[qn2 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pend_item.x + 3, pend_rec.y);
+          q2[qn2 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pend_item[0].x + 3, pend_rec[0].y | 0x80000000u);
         qn2 = uniform (qn2 + (uint32_t)__popcll (m));
         if (qn2 >= WAVE) {
           qn2 -= WAVE;
           walk_batch (WAVE);
         }
       }
-      pend_n = 0;
     }
+#pragma unroll
+    for (int d = 0; d + 1 < GRAM_DEPTH; d++) {
+      pend_item[d] = pend_item[d + 1];
+      pend_rec[d] = pend_rec[d + 1];
+      pend_n[d] = pend_n[d + 1];
+    }
+    pend_n[GRAM_DEPTH - 1] = 0;
   };
-  /* takes the newest n items of the first queue and sends for their records */
+  /* takes the newest n items of the first queue and sends for their records (the last pipeline
+   * slot is free: consume_oldest ran just before) */
   auto issue_batch = [&] (uint32_t n_items) {
     qn1 -= n_items;
-    pend_item = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
-    pend_rec = K.g4rec[pend_item.y & 0xFFFFFu];
-    pend_n = n_items;
+    pend_item[GRAM_DEPTH - 1] = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
+    pend_rec[GRAM_DEPTH - 1] = K.g4rec[pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu];
+    pend_n[GRAM_DEPTH - 1] = n_items;
   };
 
   /* one group: cur = this lane's 16 bytes, next_x = the first 4 bytes of every lane of the next group */
@@ -1617,7 +1643,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           q1[qn1 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos0 + j, idx | (c[j + 4] << 20));
         qn1 = uniform (qn1 + (uint32_t)__popcll (m));
         if (qn1 >= WAVE) {
-          consume_pending ();
+          consume_oldest ();
           issue_batch (WAVE);
         }
       }
@@ -1643,11 +1669,13 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       c3 = n3;
     }
   }
-  consume_pending ();
   if (qn1) {
+    consume_oldest ();
     issue_batch (qn1);
-    consume_pending ();
   }
+#pragma unroll
+  for (int d = 0; d < GRAM_DEPTH; d++)
+    consume_oldest ();
   if (qn2) {
     const uint32_t left = qn2;
     qn2 = 0;
