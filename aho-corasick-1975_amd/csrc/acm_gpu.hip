@@ -1104,6 +1104,11 @@ struct StartsK {
   uint32_t lut_size;
   uint32_t R;          /* groups per tile, a multiple of 4 */
   uint32_t queue_off;  /* LDS: [lut if staged][16 queues of 128][16 hit buffers of 64][tile counter] */
+  /* 4-gram kernel only: its records are laid out depth-first below depth 4 (a keyword's tail in
+   * consecutive records); an item names a depth-4 state by its breadth-first id, remap[id -
+   * remap_base] is its record, and word 0 of a record is the state's breadth-first id */
+  const uint32_t *remap;
+  uint32_t remap_base;
 };
 constexpr uint32_t ST_ALWAYS = 0x80000000u, ST_SECOND = 0x40000000u, ST_STATE = 0x3FFFFFFFu;
 
@@ -1214,64 +1219,70 @@ emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t la
   }
 }
 
-/* third sieve: up to 64 queued starts, item = (position p of the first symbol, child of the root
- * reached by it); walks the goto function from there while the text follows it */
-/* (the structs come by pointer to copies the caller makes on the spot: taking the address of
- * the kernel's own K and E would move them from scalar registers to scratch memory for the whole
- * kernel -- measured 2x on the main loop) */
-template <typename SYM, bool COUNT_ONLY>
+/* third sieve: the newest n_items (<= 64) of a wave's queue, item = (position p of the last
+ * symbol read, state reached | flags).  ONE level per call: report the state if it is terminal,
+ * look its goto edge on text[p + 1] up, and put the starts that go on back into the queue -- the
+ * few long walks (a planted keyword of 12 symbols) then travel in full batches with everybody
+ * else's instead of holding 63 idle lanes for 8 rounds of memory latency each.
+ * Returns (new queue fill << 32) | tally.
+ * (The structs come by pointer to copies the caller makes on the spot: taking the address of the
+ * kernel's own K and E would move them from scalar registers to scratch memory for the whole
+ * kernel -- measured 2x on the main loop.) */
+constexpr uint32_t WALK_CTX_K = 128, WALK_CTX_BYTES = 16 + 128 + 256; /* LDS after the tile counter: StartsK, EmitCtx */
+static_assert (sizeof (StartsK) <= WALK_CTX_K && sizeof (EmitCtx) <= 256, "walk context does not fit its LDS slot");
+constexpr uint32_t WI_REPORTED = 0x80000000u; /* what ends in this state has been reported by the caller */
+constexpr uint32_t WI_RECORD = 0x40000000u;   /* 4-gram kernel: the index is a record index already (StartsK::remap) */
+template <typename SYM, bool COUNT_ONLY, bool GRAM = false>
 __device__ __noinline__ unsigned long long
-walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, const uint2 *items, uint32_t n_items, uint2 *hits,
+walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue, uint32_t qn, uint32_t n_items, uint2 *hits,
              unsigned long long counted) {
   const StartsK &K = *Kp;
   const EmitCtx &E = *Ep;
   const uint32_t lane = lane_id ();
-  bool alive = lane < n_items;
-  const uint2 it = alive ? items[lane] : make_uint2 (0, 0);
-  uint32_t p = it.x, st = it.y & 0x7FFFFFFFu;
-  bool reported = (it.y >> 31) != 0; /* the caller has already reported what ends in the first state */
-  uint4 ra = K.srec[2 * st], rb = K.srec[2 * st + 1];
-  bool more = alive && p + 1 < E.n;
-  uint32_t c1 = more ? (uint32_t)text[p + 1] : 0u;
-  for (;;) {
-    emit_terminals<COUNT_ONLY> (E, alive && !reported && ra.w != 0 && p >= E.emit_from, p, st, lane, hits, counted);
-    reported = false;
-    uint32_t nx = NONE;
-    if (alive && more) {
-      const uint32_t ne = ra.y;
-      if (ne >= 1 && rb.x == c1)
-        nx = rb.y;
-      else if (ne >= 2 && rb.z == c1)
-        nx = rb.w;
-      else if (ne > 2) {
-        uint32_t lo = ra.z, hi = ra.z + ne;
-        while (lo < hi) {
-          const uint32_t mid = lo + (hi - lo) / 2;
-          if (K.sedge[mid].x < c1)
-            lo = mid + 1;
-          else
-            hi = mid;
-        }
-        if (lo < ra.z + ne) {
-          const uint2 e = K.sedge[lo];
-          if (e.x == c1)
-            nx = e.y;
-        }
+  const uint32_t base = qn - n_items;
+  const bool alive = lane < n_items;
+  const uint2 it = alive ? queue[base + lane] : make_uint2 (0, 0);
+  const uint32_t p = it.x;
+  uint32_t st = it.y & ST_STATE;
+  if (GRAM && !(it.y & WI_RECORD))
+    st = alive ? K.remap[st - K.remap_base] : 0u;
+  const uint4 ra = K.srec[2 * st], rb = K.srec[2 * st + 1];
+  const bool more = alive && p + 1 < E.n;
+  const uint32_t c1 = more ? (uint32_t)text[p + 1] : 0u;
+  emit_terminals<COUNT_ONLY> (E, alive && !(it.y & WI_REPORTED) && ra.w != 0 && p >= E.emit_from, p, GRAM ? ra.x : st, lane, hits,
+                              counted);
+  uint32_t nx = NONE;
+  if (more) {
+    const uint32_t ne = ra.y;
+    if (ne >= 1 && rb.x == c1)
+      nx = rb.y;
+    else if (ne >= 2 && rb.z == c1)
+      nx = rb.w;
+    else if (ne > 2) {
+      uint32_t lo = ra.z, hi = ra.z + ne;
+      while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (K.sedge[mid].x < c1)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      if (lo < ra.z + ne) {
+        const uint2 e = K.sedge[lo];
+        if (e.x == c1)
+          nx = e.y;
       }
     }
-    alive = alive && nx != NONE;
-    if (!__ballot (alive))
-      break;
-    if (alive) {
-      st = nx;
-      p++;
-      ra = K.srec[2 * st];
-      rb = K.srec[2 * st + 1];
-      more = p + 1 < E.n;
-      c1 = more ? (uint32_t)text[p + 1] : 0u;
-    }
   }
-  return counted;
+  const bool go = nx != NONE;
+  const uint64_t m = __ballot (go);
+  if (go)
+    queue[base + (uint32_t)__popcll (m & ((1ull << lane) - 1))] = make_uint2 (p + 1, nx | (GRAM ? WI_RECORD : 0u));
+  const uint32_t fill = base + (uint32_t)__popcll (m);
+  if (COUNT_ONLY)
+    return ((unsigned long long)fill << 32) | (uint32_t)counted;
+  /* record mode: the tally is the fill of the hit buffer, one value for the wave */
+  return ((unsigned long long)fill << 32) | uniform ((uint32_t)counted);
 }
 
 template <bool LUT_LDS>
@@ -1325,8 +1336,16 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
   }
   constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
   uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (QCAP + HITS_STRIDE) * 8);
-  if (threadIdx.x == 0)
+  /* what walk_starts needs of K and E, once per block in LDS: handing it the kernel's own
+   * structs by address would move them from scalar registers to scratch for the whole kernel,
+   * and a copy per call is 13 KB of scratch traffic per wave and call */
+  StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4);
+  EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
+  if (threadIdx.x == 0) {
     *next_tile = 0;
+    *Ks = K;
+    *Es = E;
+  }
   __syncthreads ();
 
   const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -1370,15 +1389,12 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
       if (deep)
         queue[qn + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (P.pos, P.child & ST_STATE);
       qn = uniform (qn + (uint32_t)__popcll (m));
-      if (qn >= WAVE) {
-        qn -= WAVE;
+      while (qn >= WAVE) {
         DIAG (const unsigned long long d_c0 = __builtin_readcyclecounter ();)
         {
-          const StartsK Kc = K;
-          const EmitCtx Ec = E;
-          counted = walk_starts<SYM, COUNT_ONLY> (&Kc, &Ec, text, queue + qn, WAVE, hits, counted);
-          if (!COUNT_ONLY)
-            counted = uniform ((uint32_t)counted); /* fill of the hit buffer: one value for the wave */
+          const unsigned long long r = walk_starts<SYM, COUNT_ONLY> (Ks, Es, text, queue, qn, WAVE, hits, counted);
+          qn = uniform ((uint32_t)(r >> 32));
+          counted = (uint32_t)r;
         }
         DIAG (d_walk += __builtin_readcyclecounter () - d_c0; d_calls++;)
       }
@@ -1452,12 +1468,10 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
 #pragma unroll
     for (uint32_t i = 0; i < PERW; i++)
       resolve (pend[w][i]);
-  if (qn) {
-    const StartsK Kc = K;
-    const EmitCtx Ec = E;
-    counted = walk_starts<SYM, COUNT_ONLY> (&Kc, &Ec, text, queue, qn, hits, counted);
-    if (!COUNT_ONLY)
-      counted = uniform ((uint32_t)counted);
+  while (qn) {
+    const unsigned long long r = walk_starts<SYM, COUNT_ONLY> (Ks, Es, text, queue, qn, qn < WAVE ? qn : WAVE, hits, counted);
+    qn = uniform ((uint32_t)(r >> 32));
+    counted = (uint32_t)r;
   }
   if (COUNT_ONLY) {
     const uint32_t incl = wave_incl_scan ((uint32_t)counted); /* a lane finds far fewer than 2^32 / 64 */
@@ -1503,8 +1517,10 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
 struct GramK {
   const uint2 *g4rec;     /* [W^4] {children mask | terminal << 31, state id of the depth-4 node (0: none)} */
   const uint32_t *g4bits; /* [g4words] one bit per 4-gram, staged in LDS */
-  const uint4 *srec;      /* trie records as in StartsK (edge symbols are raw bytes) */
+  const uint4 *srec;      /* trie records of the states of depth >= 4, depth-first order (see StartsK::remap) */
   const uint2 *sedge;
+  const uint32_t *g4gid;  /* [states of depth 4] record index of each depth-4 state */
+  uint32_t d4_begin;      /* breadth-first id of the first depth-4 state */
   uint32_t g4words;
   uint32_t W, lo, span, W4; /* class = min (byte - lo, span); W = span + 1 */
   uint32_t R;             /* groups per tile */
@@ -1525,8 +1541,18 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       dst[i] = src[i];
   }
   uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (2 * QCAP + HITS_STRIDE) * 8);
-  if (threadIdx.x == 0)
+  StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4); /* see scan_starts_kernel */
+  EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
+  if (threadIdx.x == 0) {
     *next_tile = 0;
+    StartsK Kc{};
+    Kc.srec = K.srec;
+    Kc.sedge = K.sedge;
+    Kc.remap = K.g4gid;
+    Kc.remap_base = K.d4_begin;
+    *Ks = Kc;
+    *Es = E;
+  }
   __syncthreads ();
 
   const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -1562,13 +1588,9 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     return text16[blk < last_blk ? blk : last_blk];
   };
   auto walk_batch = [&] (uint32_t n_items) {
-    StartsK Kc{};
-    Kc.srec = K.srec;
-    Kc.sedge = K.sedge;
-    const EmitCtx Ec = E;
-    counted = walk_starts<uint8_t, COUNT_ONLY> (&Kc, &Ec, text, q2 + qn2, n_items, hits, counted);
-    if (!COUNT_ONLY)
-      counted = uniform ((uint32_t)counted);
+    const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, true> (Ks, Es, text, q2, qn2, n_items, hits, counted);
+    qn2 = uniform ((uint32_t)(r >> 32));
+    counted = (uint32_t)r;
   };
   /* second sieve on the oldest pending batch: terminal, or the 5th symbol is an edge of the
    * depth-4 state; then the pipeline moves up */
@@ -1586,12 +1608,10 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       const uint64_t m = __ballot (pass);
       if (m) {
         if (pass)
-          q2[qn2 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pend_item[0].x + 3, pend_rec[0].y | 0x80000000u);
+          q2[qn2 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pend_item[0].x + 3, pend_rec[0].y | WI_REPORTED);
         qn2 = uniform (qn2 + (uint32_t)__popcll (m));
-        if (qn2 >= WAVE) {
-          qn2 -= WAVE;
+        while (qn2 >= WAVE)
           walk_batch (WAVE);
-        }
       }
     }
 #pragma unroll
@@ -1607,7 +1627,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   auto issue_batch = [&] (uint32_t n_items) {
     qn1 -= n_items;
     pend_item[GRAM_DEPTH - 1] = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
+#ifdef GRAM_EXP_NOGATHER
+    pend_rec[GRAM_DEPTH - 1] = make_uint2 (pend_item[GRAM_DEPTH - 1].y >> 3, 1);
+#else
     pend_rec[GRAM_DEPTH - 1] = K.g4rec[pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu];
+#endif
     pend_n[GRAM_DEPTH - 1] = n_items;
   };
 
@@ -1676,11 +1700,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
 #pragma unroll
   for (int d = 0; d < GRAM_DEPTH; d++)
     consume_oldest ();
-  if (qn2) {
-    const uint32_t left = qn2;
-    qn2 = 0;
-    walk_batch (left);
-  }
+  while (qn2)
+    walk_batch (qn2 < WAVE ? qn2 : WAVE);
   if (COUNT_ONLY) {
     const uint32_t incl = wave_incl_scan ((uint32_t)counted);
     const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
@@ -2059,7 +2080,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const size_t o_tpairs = blob_reserve (cur, starts ? (size_t)n * 8 : 0); /* by state id; filled for the root's children */
   /* 4-gram sieve kernel: byte alphabets of width <= 30 whose automaton is too big for the LDS
    * scheme, every keyword at least 4 symbols long */
-  bool gram = dense && entry_bytes == 4 && fi.width <= 30 && fi.width == fi.alpha_span + 1 && fi.lmax >= 4 && n < 0x7FFFFFFFu;
+  bool gram = dense && entry_bytes == 4 && fi.width <= 30 && fi.width == fi.alpha_span + 1 && fi.lmax >= 4 && n < 0x40000000u;
   if (gram) {
     for (uint32_t k = 0; k < fi.n_keywords && gram; k++)
       gram = fv.depth[fv.kw_state[k]] >= 4;
@@ -2074,6 +2095,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const size_t o_g4rec = blob_reserve (cur, gram ? (size_t)gW4 * 8 : 0);
   const size_t o_grec = blob_reserve (cur, gram ? (size_t)n * 32 : 0);
   const size_t o_gedge = blob_reserve (cur, gram ? (size_t)fi.n_edges * 8 : 0);
+  const size_t o_g4gid = blob_reserve (cur, gram ? (size_t)(fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1] - fv.depth_start[4]) * 4 + 16 : 0);
   p->blob_bytes = cur;
 
   std::vector<unsigned char> host (cur, 0);
@@ -2174,20 +2196,42 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     uint32_t *g4 = reinterpret_cast<uint32_t *> (&host[o_g4rec]);
     uint32_t *rec = reinterpret_cast<uint32_t *> (&host[o_grec]);
     uint32_t *edge = reinterpret_cast<uint32_t *> (&host[o_gedge]);
-    for (uint32_t e = 0; e < fi.n_edges; e++) {
-      edge[2 * e] = fv.edge_sym[e];
-      edge[2 * e + 1] = fv.edge_next[e];
-    }
-    for (uint32_t st = 0; st < n; st++) {
-      const uint32_t b0 = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b0;
-      uint32_t *r = rec + 8 * (size_t)st;
-      r[1] = ne;
-      r[2] = b0;
-      r[3] = fv.term_kw[st] != NONE ? 1u : 0u;
-      r[4] = ne >= 1 ? fv.edge_sym[b0] : 0;
-      r[5] = ne >= 1 ? fv.edge_next[b0] : 0;
-      r[6] = ne >= 2 ? fv.edge_sym[b0 + 1] : 0;
-      r[7] = ne >= 2 ? fv.edge_next[b0 + 1] : 0;
+    uint32_t *g4gid = reinterpret_cast<uint32_t *> (&host[o_g4gid]);
+    {
+      /* records of the states of depth >= 4 in depth-first (preorder) order, subtree after
+       * subtree of the depth-4 states: the tail of a keyword is a run of consecutive 32-byte
+       * records, so a walk touches one or two cache lines instead of one per symbol */
+      std::vector<uint32_t> gid (n, 0), stack;
+      uint32_t next_gid = 0;
+      for (uint32_t root4 = fv.depth_start[4]; root4 < fv.depth_start[5]; root4++) {
+        g4gid[root4 - fv.depth_start[4]] = next_gid;
+        stack.push_back (root4);
+        while (!stack.empty ()) {
+          const uint32_t st = stack.back ();
+          stack.pop_back ();
+          gid[st] = next_gid++;
+          for (uint32_t e = fv.row_ptr[st + 1]; e-- > fv.row_ptr[st];) /* first child on top */
+            stack.push_back (fv.edge_next[e]);
+        }
+      }
+      uint32_t slots = 0;
+      for (uint32_t st = fv.depth_start[4]; st < n; st++) {
+        const uint32_t b0 = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b0;
+        uint32_t *r = rec + 8 * (size_t)gid[st];
+        r[0] = st;
+        r[1] = ne;
+        r[2] = slots;
+        r[3] = fv.term_kw[st] != NONE ? 1u : 0u;
+        r[4] = ne >= 1 ? fv.edge_sym[b0] : 0;
+        r[5] = ne >= 1 ? gid[fv.edge_next[b0]] : 0;
+        r[6] = ne >= 2 ? fv.edge_sym[b0 + 1] : 0;
+        r[7] = ne >= 2 ? gid[fv.edge_next[b0 + 1]] : 0;
+        for (uint32_t e = b0; e < b0 + ne; e++) {
+          edge[2 * (size_t)slots] = fv.edge_sym[e];
+          edge[2 * (size_t)slots + 1] = gid[fv.edge_next[e]];
+          slots++;
+        }
+      }
     }
     /* base-W number of the path of every state down to depth 4 (parents come first in
      * breadth-first order); the depth-4 states are the 4-grams some keyword starts with */
@@ -2274,19 +2318,21 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     const uint32_t lds_total = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
     const uint32_t gq = (SPARSE_THREADS / WAVE) * (2 * QCAP + HITS_STRIDE) * 8;
     const uint32_t bits_bytes = (g4words * 4 + 15) & ~15u;
-    if ((uint64_t)bits_bytes + gq + 16 <= lds_total) {
+    if ((uint64_t)bits_bytes + gq + WALK_CTX_BYTES <= lds_total) {
       p->gram = true;
       p->GK.g4rec = reinterpret_cast<const uint2 *> (b + o_g4rec);
       p->GK.g4bits = u32p (o_g4bits);
       p->GK.srec = reinterpret_cast<const uint4 *> (b + o_grec);
       p->GK.sedge = reinterpret_cast<const uint2 *> (b + o_gedge);
+      p->GK.g4gid = u32p (o_g4gid);
+      p->GK.d4_begin = fv.depth_start[4];
       p->GK.g4words = g4words;
       p->GK.W = gW;
       p->GK.lo = fi.alpha_lo;
       p->GK.span = fi.alpha_span;
       p->GK.W4 = gW4;
       p->GK.queue_off = bits_bytes;
-      p->gram_lds_bytes = bits_bytes + gq + 16;
+      p->gram_lds_bytes = bits_bytes + gq + WALK_CTX_BYTES;
     }
   }
   if (sparse) {
@@ -2314,10 +2360,10 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       p->TK.pairs = reinterpret_cast<const uint2 *> (b + o_tpairs);
       p->TK.lut_size = lut_size;
       const uint32_t starts_queue_bytes = (SPARSE_THREADS / WAVE) * (QCAP + HITS_STRIDE) * 8;
-      p->starts_lut_lds = (uint64_t)lut_size * 4 + starts_queue_bytes + 16 <= lds_total;
+      p->starts_lut_lds = (uint64_t)lut_size * 4 + starts_queue_bytes + WALK_CTX_BYTES <= lds_total;
       p->TK.queue_off = p->starts_lut_lds ? lut_size * 4 : 0;
       p->TK.R = 0;
-      p->starts_lds_bytes = p->TK.queue_off + starts_queue_bytes + 16;
+      p->starts_lds_bytes = p->TK.queue_off + starts_queue_bytes + WALK_CTX_BYTES;
       if (p->starts) {
         StartsMirror *M = new (std::nothrow) StartsMirror ();
         if (M) {
