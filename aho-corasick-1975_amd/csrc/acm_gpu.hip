@@ -1356,10 +1356,11 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
   hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
   const SYM *text = reinterpret_cast<const SYM *> (text8);
   const uint4 *text16 = reinterpret_cast<const uint4 *> (text8);
+  /* block b takes the tiles b, b + gridDim.x, ... (match density is rarely even along a text:
+   * contiguous shares left two blocks of config 3 working 1 ms after all others had finished),
+   * handed to its waves through the LDS counter */
   const uint32_t ntiles = A.range_end - A.range_begin;
-  const uint32_t tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
-  const uint32_t blk_begin = blockIdx.x * tiles_per_block;
-  const uint32_t blk_tiles = blk_begin >= ntiles ? 0 : (ntiles - blk_begin < tiles_per_block ? ntiles - blk_begin : tiles_per_block);
+  const uint32_t blk_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
   const uint32_t last_blk = (uint32_t)(((uint64_t)A.n * sizeof (SYM) - 1) / 16);
   uint32_t qn = 0;
   unsigned long long counted = 0;
@@ -1448,7 +1449,7 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
     if (t >= blk_tiles)
       break;
     DIAG (d_tiles++;)
-    const uint32_t g0 = (A.range_begin + blk_begin + t) * K.R;
+    const uint32_t g0 = (A.range_begin + t * gridDim.x + blockIdx.x) * K.R;
     uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
     for (uint32_t k = 0; k < K.R; k += 4) {
       const uint32_t g = g0 + k;
@@ -1563,10 +1564,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   const uint32_t wave_id = blockIdx.x * WAVES + wib;
   hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
   const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
+  /* block b takes the tiles b, b + gridDim.x, ... (match density is rarely even along a text:
+   * contiguous shares left two blocks of config 3 working 1 ms after all others had finished),
+   * handed to its waves through the LDS counter */
   const uint32_t ntiles = A.range_end - A.range_begin;
-  const uint32_t tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
-  const uint32_t blk_begin = blockIdx.x * tiles_per_block;
-  const uint32_t blk_tiles = blk_begin >= ntiles ? 0 : (ntiles - blk_begin < tiles_per_block ? ntiles - blk_begin : tiles_per_block);
+  const uint32_t blk_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
   const uint32_t last_blk = (A.n - 1) / 16;
   uint32_t qn1 = 0, qn2 = 0;
   unsigned long long counted = 0;
@@ -1574,6 +1576,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
    * (the gather of a batch has the time it takes the scan to fill that many more before it is
    * looked at: one batch ahead left the L2 / MALL latency exposed) */
   constexpr int GRAM_DEPTH = 3;
+  DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_items = 0, d_b1 = 0, d_cons = 0, d_tiles = 0;)
   uint2 pend_item[GRAM_DEPTH], pend_rec[GRAM_DEPTH];
   uint32_t pend_n[GRAM_DEPTH]; /* wave-uniform: items in each pending batch, [0] the oldest */
 #pragma unroll
@@ -1588,9 +1591,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     return text16[blk < last_blk ? blk : last_blk];
   };
   auto walk_batch = [&] (uint32_t n_items) {
+    DIAG (const unsigned long long d_c0 = __builtin_readcyclecounter ();)
     const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, true> (Ks, Es, text, q2, qn2, n_items, hits, counted);
     qn2 = uniform ((uint32_t)(r >> 32));
     counted = (uint32_t)r;
+    DIAG (d_walk += __builtin_readcyclecounter () - d_c0; d_calls++; d_items += n_items;)
   };
   /* second sieve on the oldest pending batch: terminal, or the 5th symbol is an edge of the
    * depth-4 state; then the pipeline moves up */
@@ -1667,8 +1672,10 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           q1[qn1 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos0 + j, idx | (c[j + 4] << 20));
         qn1 = uniform (qn1 + (uint32_t)__popcll (m));
         if (qn1 >= WAVE) {
+          DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)
           consume_oldest ();
           issue_batch (WAVE);
+          DIAG (d_cons += __builtin_readcyclecounter () - d_c1; d_b1++;)
         }
       }
       idx = idx * K.W + c[j + 4] - c[j] * K.W4;
@@ -1682,7 +1689,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     t = uniform (t);
     if (t >= blk_tiles)
       break;
-    const uint32_t g0 = (A.range_begin + blk_begin + t) * K.R;
+    DIAG (d_tiles++;)
+    const uint32_t g0 = (A.range_begin + t * gridDim.x + blockIdx.x) * K.R;
     uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
     for (uint32_t k = 0; k < K.R; k++) {
       const uint4 n3 = load_group (g0 + k + 4);
@@ -1713,6 +1721,17 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     if (lane == 0 && fill)
       fill[wave_id] = hits[-1].y;
   }
+  DIAG (if (lane == 0 && wave_id < 8192) {
+    unsigned long long *o = g_acm_diag[wave_id];
+    o[0] = __builtin_readcyclecounter () - d_t0;
+    o[1] = d_walk;
+    o[2] = d_calls;
+    o[3] = d_items;
+    o[4] = d_b1;
+    o[5] = d_cons;
+    o[6] = wall_clock64 ();
+    o[7] = d_tiles;
+  })
 }
 
 /* ------------------------------------------------------------------ comparator classes
