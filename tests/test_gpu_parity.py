@@ -568,3 +568,66 @@ def test_gram_kernel_small_alphabet_dense_matches(torch_cuda):
         rb = max(b - (m.lmax - 1), 0)
         got = plan.scan_sorted(dev[rb:e], emit_from=b - rb, pos_base=rb)
         assert np.array_equal(got, want[(want["end_pos"] >= b) & (want["end_pos"] < e)]), (b, e)
+
+
+def _random_case(rng, kind):
+    """Random dictionary + text meant for one kernel family; returns (keywords, text, sym_bytes, env)."""
+    if kind == "dense":            # byte alphabet, few states: continuation-mode dense kernel
+        lo = int(rng.integers(0, 200)); span = int(rng.integers(1, 40))
+        kws = [rng.integers(lo, lo + span, size=rng.integers(1, 14)).astype(np.uint8) for _ in range(int(rng.integers(1, 300)))]
+        text = rng.integers(max(lo - 2, 0), min(lo + span + 2, 256), size=int(rng.integers(1, 200000))).astype(np.uint8)
+        return kws, text, 1, {}
+    if kind in ("gram", "sticky"):  # small alphabet, > 32768 states, keywords >= 4 symbols
+        span = int(rng.integers(5, 10))
+        kws = [rng.integers(97, 97 + span, size=rng.integers(4, 13)).astype(np.uint8) for _ in range(int(rng.integers(11000, 14000)))]
+        text = rng.integers(96, 97 + span + 1, size=int(rng.integers(50000, 400000))).astype(np.uint8)
+        return kws, text, 1, ({"ACM_GPU_GRAM": "0"} if kind == "sticky" else {})
+    if kind == "short":             # > 32768 states but keywords shorter than 4: not eligible for the 4-gram kernel
+        kws = [rng.integers(97, 123, size=rng.integers(1, 12)).astype(np.uint8) for _ in range(int(rng.integers(7000, 9000)))]
+        text = rng.integers(97, 123, size=int(rng.integers(50000, 300000))).astype(np.uint8)
+        return kws, text, 1, {}
+    sym = 2 if kind.endswith("16") else 4
+    dt = np.uint16 if sym == 2 else np.uint32
+    V = int(rng.integers(5, 3000))
+    kws = [rng.integers(0, V, size=rng.integers(1, 9)).astype(dt) for _ in range(int(rng.integers(1, 2000)))]
+    text = rng.integers(0, V + 3, size=int(rng.integers(1, 200000))).astype(dt)
+    return kws, text, sym, ({"ACM_GPU_SPARSE": "walk"} if kind.startswith("walk") else {})
+
+
+@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "gram", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
+                                       for s in range(3)])
+def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed):
+    """Random dictionaries and texts through every kernel family; whole scans, count-only scans and
+    random shards (emit_from, pos_base, odd offsets and lengths) against the oracle."""
+    rng = np.random.default_rng(1000 * seed + sum(map(ord, kind)))
+    kws, text, sym, env = _random_case(rng, kind)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    # plant some keywords so that long matches exist
+    for _ in range(min(200, text.size // 50)):
+        w = kws[int(rng.integers(0, len(kws)))]
+        if w.size < text.size:
+            at = int(rng.integers(0, text.size - w.size))
+            text[at:at + w.size] = w
+    m, o = build_pair(kws, sym)
+    plan = m.plan(0)
+    expect = {"dense": 1, "gram": 5, "sticky": 1, "short": 1, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
+    if kind in ("gram", "sticky", "short"):
+        assert plan.info.dense_rows > 32768, "the generator is meant to give more states than the LDS scheme takes"
+    assert plan.info.kernel == expect, (kind, plan.info.kernel)
+    want = o.scan(text)
+    dev = _dev(torch_cuda, text)
+    got = plan.scan_sorted(dev)
+    assert got.size == want.size and np.array_equal(got, want)
+    assert int(plan.count(dev).item()) == want.size
+    lmax = m.lmax
+    for _ in range(6):
+        b = int(rng.integers(0, text.size))
+        e = int(rng.integers(b, min(text.size, b + 70000))) + 1
+        e = min(e, text.size)
+        rb = max(b - (lmax - 1), 0)
+        base = int(rng.integers(0, 1 << 40))
+        got = plan.scan_sorted(dev[rb:e], emit_from=b - rb, pos_base=base)
+        sel = want[(want["end_pos"] >= b) & (want["end_pos"] < e)].copy()
+        sel["end_pos"] += base - rb
+        assert np.array_equal(got, sel), (kind, seed, b, e)
