@@ -1,27 +1,28 @@
 /*
- * acm_gpu.hip -- device side of the bulk scan (include/acm_gpu.h) for MI355X / gfx950.
+ * acm_gpu.hip -- the bulk scan (include/acm_gpu.h) for MI355X / gfx950: device plan, launches,
+ * streaming, canonical sort and the C ABI; the kernels are in the dev_*.h files included below
+ * (one translation unit).
  *
- * What runs here is the reference's caller loop (examples/test.c:17-23): per input symbol one
- * automaton step (acm_match -> state_goto, aho_corasick.c:434-448,167-192) and, when the new
- * state has outputs, the walk over keyword-terminal states of its failure chain
- * (acm_get_match, aho_corasick.c:459-466), emitting one 16-byte record per match.
+ * What runs on the device is the reference's caller loop (examples/test.c:17-23): per input
+ * symbol one automaton step (acm_match -> state_goto, aho_corasick.c:434-448,167-192) and, when
+ * the new state has outputs, the walk over the keyword-terminal states of its failure chain
+ * (acm_get_match, aho_corasick.c:459-466), one 16-byte record per match.
  *
- * Kernels
- *   scan_dense_kernel  byte alphabets.  One workgroup of 16 waves per CU keeps the automaton in
- *                      LDS in two forms: failure-resolved rows (one ds_read per symbol) for the
- *                      shallow, hot states and 8-byte {child, failure} records for deep states
- *                      with at most one child; states that fit neither are walked through the
- *                      HBM/L2-resident failure-resolved rows.  A wave owns tiles of 64*S*C
- *                      contiguous bytes; each lane walks S independent chunks of C bytes held in
- *                      registers (dwordx4 loads), restarting from the root >= lmax-1 bytes
- *                      before its chunk and reporting only matches that end inside the chunk.
- *   scan_csr_kernel    any symbol width (1/2/4 bytes): goto/failure walk over the CSR arrays.
- *   flush_queue        states-with-outputs are queued per wave in LDS as (position, state) and
- *                      expanded to records with one global atomic per <= 64 queue entries
- *                      (wave prefix sum), never one atomic per match.
- *   sort               canonical order (end_pos asc, length desc) by a 64-bit radix sort
- *                      (hipCUB, a library op outside the timed scan).
- * No MFMA anywhere: this is byte/integer pointer chasing bound by LDS lookups and HBM reads.
+ * Kernels (DESIGN.md section 4)
+ *   dev_dense.h   scan_dense_kernel   byte alphabets, <= 32,768 states: failure-resolved rows of the
+ *                                     hot states in LDS, one ds_read_u16 per symbol, continuation
+ *                                     items for the rest (config 2: the headline kernel); sticky
+ *                                     mode with rows in HBM for bigger dictionaries
+ *   dev_gram.h    scan_gram_kernel    byte alphabets, big dictionaries of keywords >= 4 symbols:
+ *                                     4-gram bit table in LDS, every position tested on its own
+ *   dev_starts.h  scan_starts_kernel  2- and 4-byte symbols: root table by symbol value in LDS,
+ *                                     every position tested on its own; walk_starts, hit parking
+ *   dev_sparse.h  scan_sparse_kernel  2- and 4-byte symbols, automaton walk (ACM_GPU_SPARSE=walk)
+ *   dev_csr.h     scan_csr_kernel     any width and alignment: goto/failure walk over CSR rows
+ *   dev_emit.h    queue items -> records: put_outputs, walk_continuation, flush_queue,
+ *                 expand_items_kernel (block-wide prefix sum, one atomic per round)
+ *   dev_misc.h    classmap (comparator classes), patch (incremental updates), sort keys, synthetic text
+ * No MFMA anywhere: this is byte/integer table walking bound by LDS lookups and HBM reads.
  */
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -45,10 +46,9 @@
     }                                                                                              \
   } while (0)
 
-/* Diagnostic build only (-DACM_DIAG, libac75_amd_diag.so, used by tools/): per-wave cycle stamps.
- * [0] kernel cycles, [1] cycles inside flush_queue, [2] flush calls, [3] slow-side steps,
- * [4] cycles inside the slow side (flushes included), [5] cycles waiting for the tile's text,
- * [6] tiles.  Nothing of this exists in the product build. */
+/* Diagnostic build only (-DACM_DIAG, libac75_amd_diag.so, used by tools/diag_*.py): eight per-wave
+ * counters (cycle stamps, call counts) whose meaning each kernel defines where it writes them.
+ * Nothing of this exists in the product build. */
 #ifdef ACM_DIAG
 __device__ unsigned long long g_acm_diag[8192][8];
 #define DIAG(...) __VA_ARGS__
@@ -123,1704 +123,13 @@ constexpr uint32_t IT_K_SHIFT = 16;     /* 12 bits: run-over step k (symbols pas
 constexpr uint32_t IT_RUN = 1u << 28;   /* queued during a chunk's run-over */
 constexpr uint32_t IT_OUT = 1u << 29;   /* report the outputs of the state itself at pos */
 
-/* ------------------------------------------------------------------ wave helpers */
-__device__ __forceinline__ uint32_t
-lane_id () {
-  return __builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u));
-}
-
-__device__ __forceinline__ uint32_t
-uniform (uint32_t v) { /* tells the compiler the value is the same in every lane */
-  return __builtin_amdgcn_readfirstlane (v);
-}
-
-__device__ __forceinline__ uint32_t
-wave_incl_scan (uint32_t v) {
-#pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) {
-    uint32_t o = __shfl_up (v, d, WAVE);
-    if ((int)lane_id () >= d)
-      v += o;
-  }
-  return v;
-}
-
-/* outputs of state st longer than `bound`, in acm_get_match index order (longest first:
- * reference aho_corasick.c:459-466): counted, and written from offset o when WRITE.  `oi` is
- * oinfo[st], already loaded by the caller. */
-template <bool WRITE>
-__device__ __forceinline__ uint32_t
-put_outputs (const EmitCtx &E, uint4 oi, uint32_t pos, uint32_t bound, uint64_t o) {
-  uint32_t cnt = 0;
-  for (uint32_t left = oi.x; left; left--) {
-    if (oi.z <= bound)
-      break;
-    if (WRITE && o + cnt < E.capacity) {
-      const uint64_t gp = E.pos_base + pos;
-      *reinterpret_cast<uint4 *> (&E.records[o + cnt]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), oi.z, oi.w);
-    }
-    cnt++;
-    if (left > 1)
-      oi = E.oinfo[oi.y];
-  }
-  return cnt;
-}
-
-/* what the walk of a continuation item found (it rarely finds more than one match position) */
-struct ContResult {
-  uint32_t cnt;      /* records in all */
-  uint32_t events;   /* positions with records */
-  uint32_t ev_pos, ev_bound; /* the first of them ... */
-  uint4 ev_oi;               /* ... and the oinfo of the state reached there */
-};
-
-/* Ownership in the continuation-mode dense kernel: a match belongs to the chunk in which it
- * STARTS.  A lane starts from the root at the first byte of its chunk [cs, ce), walks the chunk
- * and then runs over into the following bytes until its state is no deeper than the number of
- * bytes past ce (no match that started before ce can still be open); during that run-over only
- * outputs longer than the bytes past ce are its own.
- *
- * Continuation item: at `pos` the lane stepped into a state s that has no row in LDS and carried
- * on from hotfail(s), the longest suffix state that has one (depth dh).  From there it still finds
- * every match that starts within the last dh symbols or later; the ones it can no longer see
- * started earlier and end after pos.  They are recovered here by walking on from s itself
- * through the HBM rows: j symbols later every output longer than j + dh -- and, past ce, longer
- * than the bytes past ce -- is such a match, and once the state is no deeper than that bound
- * nothing more can be missing.
- * One dependent load per symbol: the row entry carries the next state, its output flag and its
- * depth; the text byte of the following step is fetched alongside. */
-__device__ __forceinline__ uint32_t
-item_chunk_end (const EmitCtx &E, uint2 it) {
-  return (it.y & IT_RUN) ? it.x + 1 - ((it.y >> IT_K_SHIFT) & 0xFFFu) : (it.x | (E.chunk - 1)) + 1;
-}
-
-template <bool WRITE>
-__device__ __forceinline__ ContResult
-walk_continuation (const EmitCtx &E, uint2 it, uint64_t o) {
-  ContResult r = { 0, 0, 0, 0, make_uint4 (0, 0, 0, 0) };
-  const uint32_t pos = it.x, st = it.y & IT_STATE;
-  const uint32_t dh = E.cont_dh[st];
-  const uint32_t ce = item_chunk_end (E, it);
-  uint32_t s2 = st;
-  uint32_t byte = pos + 1 < E.n ? E.text[pos + 1] : 0;
-  for (uint32_t j = 1; pos + j < E.n; j++) {
-    const uint32_t p = pos + j;
-    const uint32_t ent = E.wrows[s2 * E.W + min (byte - E.lo, E.span)];
-    byte = p + 1 < E.n ? E.text[p + 1] : 0;
-    s2 = ent & IT_STATE;
-    const uint32_t past = p + 1 > ce ? p + 1 - ce : 0;
-    const uint32_t bound = j + dh > past ? j + dh : past;
-    if ((ent >> 16) <= bound)
-      break;
-    if ((ent & 0x8000u) && p >= E.emit_from) {
-      const uint4 oi = E.oinfo[s2];
-      const uint32_t c = put_outputs<WRITE> (E, oi, p, bound, o + r.cnt);
-      if (c) {
-        if (!r.events) {
-          r.ev_pos = p;
-          r.ev_oi = oi;
-          r.ev_bound = bound;
-        }
-        r.events++;
-        r.cnt += c;
-      }
-    }
-  }
-  return r;
-}
-
-/* number of records of one queue item (walks its continuation, remembering what it found) */
-template <bool CONT>
-__device__ __forceinline__ uint32_t
-item_count (const EmitCtx &E, bool valid, uint2 it, uint32_t &own_cnt, uint4 &own_oi, ContResult &r) {
-  const uint32_t st = CONT ? (it.y & IT_STATE) : it.y;
-  if (valid && st >= E.n_states) { /* cannot happen; never index the tables with it */
-    if (E.error)
-      *E.error = 1;
-    valid = false;
-  }
-  const bool own = valid && (!CONT || (it.y & IT_OUT));
-  own_cnt = 0;
-  own_oi = make_uint4 (0, 0, 0, 0);
-  if (own) {
-    own_oi = E.oinfo[st];
-    if (CONT && (it.y & IT_RUN)) /* run-over: only outputs longer than the bytes past the chunk */
-      own_cnt = put_outputs<false> (E, own_oi, it.x, (it.y >> IT_K_SHIFT) & 0xFFFu, 0);
-    else
-      own_cnt = own_oi.x;
-  }
-  r = ContResult{ 0, 0, 0, 0, make_uint4 (0, 0, 0, 0) };
-  if (CONT && valid && (it.y & IT_CONT))
-    r = walk_continuation<false> (E, it, 0);
-  return own_cnt + r.cnt;
-}
-
-/* writes them from offset o: the state's own outputs first, then the continuation's */
-template <bool CONT>
-__device__ __forceinline__ void
-item_write (const EmitCtx &E, uint2 it, uint32_t own_cnt, uint4 own_oi, const ContResult &r, uint64_t o) {
-  if (own_cnt)
-    (void)put_outputs<true> (E, own_oi, it.x, (CONT && (it.y & IT_RUN)) ? ((it.y >> IT_K_SHIFT) & 0xFFFu) : 0u, o);
-  if (r.events == 1)
-    (void)put_outputs<true> (E, r.ev_oi, r.ev_pos, r.ev_bound, o + own_cnt);
-  else if (r.events > 1)
-    (void)walk_continuation<true> (E, it, o + own_cnt);
-}
-
-/* Expand a wave's queue into records: one global atomic per <= 64 items (wave prefix sum of the
- * per-item counts), records of one item contiguous.  Must be called by all 64 lanes. */
-template <bool CONT, bool COUNT_ONLY>
-__device__ __noinline__ void
-flush_queue (EmitCtx E, const uint2 *queue, uint32_t n_items) {
-  const uint32_t lane = lane_id ();
-  for (uint32_t base = 0; base < n_items; base += WAVE) {
-    const uint32_t i = base + lane;
-    const bool valid = i < n_items;
-    const uint2 it = valid ? queue[i] : make_uint2 (0, 0);
-    uint32_t own_cnt;
-    uint4 own_oi;
-    ContResult r;
-    const uint32_t cnt = item_count<CONT> (E, valid, it, own_cnt, own_oi, r);
-    const uint32_t incl = wave_incl_scan (cnt);
-    const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
-    unsigned long long gbase = 0;
-    if (lane == 0 && total)
-      gbase = atomicAdd (E.count, (unsigned long long)total);
-    gbase = ((unsigned long long)__shfl ((uint32_t)(gbase >> 32), 0, WAVE) << 32) | __shfl ((uint32_t)gbase, 0, WAVE);
-    if (!COUNT_ONLY && cnt)
-      item_write<CONT> (E, it, own_cnt, own_oi, r, gbase + (incl - cnt));
-  }
-}
-
-/* Where a wave of the dense kernel parks its queue when it fills up: a private region of the
- * plan's item buffer in HBM (plain coalesced stores, nothing to wait for).  expand_items_kernel
- * turns the parked items into records afterwards with the whole chip's parallelism; a wave whose
- * region is full expands in place instead (flush_queue), so nothing is ever dropped. */
-struct Spill {
-  uint2 *region;     /* this wave's region */
-  uint32_t capacity; /* items per region */
-  uint32_t fill;     /* items parked so far (wave-uniform) */
-};
-
-template <bool CONT, bool COUNT_ONLY>
-__device__ __forceinline__ void
-queue_drain (const EmitCtx &E, const uint2 *queue, uint32_t qn, Spill *sp, uint32_t lane) {
-  if (sp && sp->fill + qn <= sp->capacity) {
-    for (uint32_t i = lane; i < qn; i += WAVE)
-      sp->region[sp->fill + i] = queue[i];
-    sp->fill = uniform (sp->fill + qn);
-  } else
-    flush_queue<CONT, COUNT_ONLY> (E, queue, qn);
-}
-
-/* append one item per lane with `hit`; wave-uniform bookkeeping in qn */
-template <bool CONT, bool COUNT_ONLY>
-__device__ __forceinline__ void
-queue_push (const EmitCtx &E, uint2 *queue, uint32_t &qn, bool hit, uint32_t pos, uint32_t word, uint32_t lane,
-            Spill *sp = nullptr) {
-  const uint64_t m = __ballot (hit);
-  if (m) {
-    if (hit)
-      queue[qn + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos, word);
-    qn = uniform (qn + (uint32_t)__popcll (m));
-    if (qn > QCAP - WAVE) {
-      queue_drain<CONT, COUNT_ONLY> (E, queue, qn, sp, lane);
-      qn = 0;
-    }
-  }
-}
-
-/* Expands the items parked by REGIONS consecutive waves of the dense kernel: THREADS threads take
- * THREADS items per round, a block-wide prefix sum of the per-item record counts gives every item
- * its slot, and ONE global atomic per round reserves the records (a single counter sustains only
- * ~90 atomics per microsecond, so they are kept to a few hundred per launch).
- * The launch leaves its own bookkeeping clean: each block zeroes the fill counters it consumed,
- * and the block that finishes last hands the total to the caller's counter (when this is the
- * last segment of a scan) and resets the running total and the ticket. */
-struct ExpandTail {
-  unsigned long long *user_count; /* where the caller wants the total */
-  unsigned int *ticket;
-  int last_segment;
-};
-
-template <bool CONT, bool COUNT_ONLY, int THREADS, int REGIONS>
-__global__ __launch_bounds__ (THREADS) void
-expand_items_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint32_t *fill, ExpandTail tail) {
-  __shared__ uint32_t s_off[REGIONS + 1];
-  __shared__ uint32_t s_wave[THREADS / WAVE];
-  __shared__ unsigned long long s_base;
-  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-  if (tid < REGIONS) { /* fill counters of this block's regions: read and zero them in parallel */
-    s_off[tid + 1] = fill[blockIdx.x * REGIONS + tid];
-    fill[blockIdx.x * REGIONS + tid] = 0;
-  }
-  __syncthreads ();
-  if (tid == 0) {
-    uint32_t acc = 0;
-    for (int r = 0; r < REGIONS; r++) {
-      const uint32_t v = s_off[r + 1];
-      s_off[r] = acc;
-      acc += v;
-    }
-    s_off[REGIONS] = acc;
-  }
-  __syncthreads ();
-  const uint32_t total = s_off[REGIONS];
-  for (uint32_t base = 0; base < total; base += THREADS) {
-    const uint32_t i = base + tid;
-    const bool valid = i < total;
-    uint2 it = make_uint2 (0, 0);
-    if (valid) {
-      uint32_t r = 0;
-#pragma unroll
-      for (int k = 1; k < REGIONS; k++)
-        r += s_off[k] <= i ? 1u : 0u;
-      it = items[(size_t)(blockIdx.x * REGIONS + r) * region_items + (i - s_off[r])];
-    }
-    uint32_t own_cnt;
-    uint4 own_oi;
-    ContResult res;
-    const uint32_t cnt = item_count<CONT> (E, valid, it, own_cnt, own_oi, res);
-    const uint32_t incl = wave_incl_scan (cnt);
-    if (lane == WAVE - 1)
-      s_wave[wid] = incl;
-    __syncthreads ();
-    if (tid == 0) {
-      uint32_t acc = 0;
-      for (int k = 0; k < THREADS / WAVE; k++) {
-        const uint32_t v = s_wave[k];
-        s_wave[k] = acc;
-        acc += v;
-      }
-      s_base = acc ? atomicAdd (E.count, (unsigned long long)acc) : 0ull;
-    }
-    __syncthreads ();
-    if (!COUNT_ONLY && cnt)
-      item_write<CONT> (E, it, own_cnt, own_oi, res, s_base + s_wave[wid] + (incl - cnt));
-    __syncthreads ();
-  }
-  if (tid == 0) {
-    /* this block's adds to the running total have returned (their values were used), so the block
-     * that draws the last ticket sees every add */
-    if (atomicAdd (tail.ticket, 1u) == gridDim.x - 1) {
-      *tail.ticket = 0;
-      if (tail.last_segment) {
-        *tail.user_count = atomicAdd (E.count, 0ull);
-        *E.count = 0;
-      }
-    }
-  }
-}
-
-/* ------------------------------------------------------------------ dense byte kernel
- * ENTRY = uint16_t: "continuation mode".  LDS holds the rows of the HD shallowest states and, for
- *   every other state s, hotfail(s).  A lane never sits in a rowless state: stepping into one
- *   queues a continuation item and the lane carries on from hotfail(s) (walk_continuation explains why
- *   nothing is lost).  The per-symbol path is: class, one ds_read_u16, compare, branch.
- * ENTRY = uint32_t: "sticky mode" for dictionaries with more than 32768 states.  LDS holds the
- *   rows of a breadth-first prefix; a lane in a deeper state is walked through the HBM rows on
- *   the slow side until it comes back. */
-template <typename ENTRY> struct EntryTraits;
-template <> struct EntryTraits<uint16_t> {
-  static constexpr uint32_t FLAG = 0x8000u;
-  static constexpr bool CONT = true;
-};
-template <> struct EntryTraits<uint32_t> {
-  static constexpr uint32_t FLAG = 0x80000000u;
-  static constexpr bool CONT = false;
-};
-
-/* per-wave walking state of the dense kernel */
-template <int S> struct Walk {
-  uint32_t s[S];   /* current state of each stream */
-  uint32_t qn;     /* queue fill (wave-uniform) */
-  uint32_t sticky; /* sticky mode, per lane: ~0 while one of its streams sits in a rowless state */
-  Spill spill;
-  DIAG (unsigned long long d_slow_cycles = 0; unsigned long long d_slow_steps = 0;)
-};
-
-template <typename ENTRY>
-__device__ __forceinline__ uint32_t
-lds_row_entry (uint32_t state, uint32_t rowbytes, uint32_t cls) {
-  /* the rows start at LDS address 0 (no static LDS in this kernel): address the LDS by integer
-   * so that no base is added per lookup */
-  const uint32_t addr = __umul24 (state, rowbytes) + cls * (uint32_t)sizeof (ENTRY);
-  return *reinterpret_cast<const __attribute__ ((address_space (3))) ENTRY *> (addr);
-}
-
-/* where a step is: pos0 = position of stream 0's byte; phase MAIN (inside the chunk), WARM
- * (sticky mode: before the chunk, nothing is reported) or RUN (continuation mode: k bytes past
- * the chunk, live_from = first state id of depth k + 1) */
-enum { PH_MAIN = 0, PH_WARM = 1, PH_RUN = 2 };
-struct StepAt {
-  uint32_t pos0, k, live_from;
-  int phase;
-};
-
-/* Slow side of one step: the whole wave comes here when some lane looked up an entry >= HD (next
- * state has outputs and/or no row in LDS), or -- sticky mode -- sits in a rowless state. */
-template <typename ENTRY, int S, bool COUNT_ONLY>
-__device__ __forceinline__ void
-dense_step_slow (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emit_end,
-                 const ENTRY *__restrict__ gdense, uint2 *queue, Walk<S> &w, uint32_t (&e)[S], const uint32_t (&cls)[S],
-                 const StepAt at, uint32_t lane) {
-  constexpr uint32_t FLAG = EntryTraits<ENTRY>::FLAG;
-  constexpr uint32_t IDMASK = FLAG - 1;
-  constexpr bool CONT = EntryTraits<ENTRY>::CONT;
-  bool rowless = false;
-  uint32_t ns[S], carry[S];
-  /* first all the loads, so that their latencies overlap with the queue bookkeeping below */
-#pragma unroll
-  for (int q = 0; q < S; q++) {
-    if (!CONT && w.s[q] >= K.HD) /* sticky mode: the LDS lookup was meaningless, redo it from HBM */
-      e[q] = gdense[w.s[q] * K.W + cls[q]];
-  }
-#pragma unroll
-  for (int q = 0; q < S; q++) {
-    ns[q] = e[q] & IDMASK;
-    carry[q] = ns[q];
-    if (CONT && ns[q] >= K.HD) /* the lane carries on from the nearest state that has a row */
-      carry[q] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint16_t *> (K.aux_off + (ns[q] - K.HD) * 2u);
-  }
-#pragma unroll
-  for (int q = 0; q < S; q++) {
-    const uint32_t pos = at.pos0 + (uint32_t)q * K.stream_stride;
-    const bool window = pos >= emit_from && pos < emit_end;
-    if (CONT) {
-      /* run-over: a lane whose state is no deeper than k has nothing of its own left */
-      const bool live = at.phase != PH_RUN || ns[q] >= at.live_from;
-      const bool out = live && (e[q] & FLAG) && window;
-      const bool deep = live && ns[q] >= K.HD && pos < emit_end;
-      uint32_t word = ns[q] | (deep ? IT_CONT : 0u) | (out ? IT_OUT : 0u);
-      if (at.phase == PH_RUN)
-        word |= IT_RUN | (at.k << IT_K_SHIFT);
-      queue_push<CONT, COUNT_ONLY> (E, queue, w.qn, out | deep, pos, word, lane, &w.spill);
-    } else {
-      const bool out = at.phase == PH_MAIN && (e[q] & FLAG) && window;
-      queue_push<CONT, COUNT_ONLY> (E, queue, w.qn, out, pos, ns[q], lane, &w.spill);
-      rowless |= ns[q] >= K.HD;
-    }
-    w.s[q] = carry[q];
-  }
-  if (!CONT)
-    w.sticky = rowless ? ~0u : 0u;
-}
-
-/* One step of all S streams of a lane: byte b[q] for stream q.
- * Fast side per stream: class = min(byte - lo, span); one ds_read at row(state) + class; all
- * streams share one compare-and-branch. */
-template <typename ENTRY, int S, bool COUNT_ONLY>
-__device__ __forceinline__ void
-dense_step (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emit_end, const ENTRY *__restrict__ gdense,
-            uint2 *queue, Walk<S> &w, const uint32_t (&b)[S], const StepAt at, uint32_t lane) {
-  uint32_t cls[S], e[S];
-#pragma unroll
-  for (int q = 0; q < S; q++) {
-    cls[q] = min (b[q] - K.lo, K.span);
-    e[q] = lds_row_entry<ENTRY> (w.s[q], K.rowbytes, cls[q]);
-  }
-  uint32_t emax = EntryTraits<ENTRY>::CONT ? 0u : w.sticky;
-#pragma unroll
-  for (int q = 0; q < S; q++)
-    emax = max (emax, e[q]);
-  if (__builtin_expect (__ballot (emax >= K.HD) != 0, 0)) {
-    DIAG (const unsigned long long t0_ = __builtin_readcyclecounter ();)
-    dense_step_slow<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, e, cls, at, lane);
-    DIAG (w.d_slow_cycles += __builtin_readcyclecounter () - t0_; w.d_slow_steps++;)
-  } else {
-#pragma unroll
-    for (int q = 0; q < S; q++)
-      w.s[q] = e[q];
-  }
-}
-
-/* 16 steps over one 16-byte block per stream; at = where the block's first byte is */
-template <typename ENTRY, int S, bool COUNT_ONLY>
-__device__ __forceinline__ void
-dense_block (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emit_end, const ENTRY *__restrict__ gdense,
-             uint2 *queue, Walk<S> &w, const uint4 (&blk)[S], const StepAt at, uint32_t lane) {
-#define ACM_BYTE(COMP, SH, J)                                                                      \
-  {                                                                                                \
-    uint32_t b_[S];                                                                                \
-    _Pragma ("unroll") for (int q = 0; q < S; q++) b_[q] = (blk[q].COMP >> (SH)) & 0xffu;          \
-    const StepAt at_ = { at.pos0 + (J), 0, 0, at.phase };                                          \
-    dense_step<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, b_, at_, lane); \
-  }
-#define ACM_WORD(COMP, J)                                                                          \
-  ACM_BYTE (COMP, 0, (J) + 0) ACM_BYTE (COMP, 8, (J) + 1) ACM_BYTE (COMP, 16, (J) + 2) ACM_BYTE (COMP, 24, (J) + 3)
-  ACM_WORD (x, 0) ACM_WORD (y, 4) ACM_WORD (z, 8) ACM_WORD (w, 12)
-#undef ACM_WORD
-#undef ACM_BYTE
-}
-
-/* compile-time loop over the C/16 blocks of a chunk (keeps the text registers statically indexed) */
-template <typename ENTRY, int S, bool COUNT_ONLY, int K0, int KN> struct BlockLoop {
-  static __device__ __forceinline__ void
-  run (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emit_end, const ENTRY *__restrict__ gdense,
-       uint2 *queue, Walk<S> &w, const uint4 (&d)[KN][S], uint32_t pos0, uint32_t lane) {
-    const StepAt at = { pos0 + 16 * K0, 0, 0, PH_MAIN };
-    dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[K0], at, lane);
-    BlockLoop<ENTRY, S, COUNT_ONLY, K0 + 1, KN>::run (K, E, emit_from, emit_end, gdense, queue, w, d, pos0, lane);
-  }
-};
-template <typename ENTRY, int S, bool COUNT_ONLY, int KN> struct BlockLoop<ENTRY, S, COUNT_ONLY, KN, KN> {
-  static __device__ __forceinline__ void
-  run (const DenseK &, const EmitCtx &, uint32_t, uint32_t, const ENTRY *__restrict__, uint2 *, Walk<S> &,
-       const uint4 (&)[KN][S], uint32_t, uint32_t) {}
-};
-
-/* Tiles [range_begin, range_end) of 64*S*C bytes cover the whole segment, the last one possibly
- * ragged.  16-byte loads are clamped to the last block that holds a valid byte (an aligned
- * 16-byte block never straddles a page, so it cannot fault); what a lane walks beyond the end of
- * the segment is never reported (emit window [emit_from, n)).
- * LDS image: [HD rows][continuation mode: hotfail of every other state, 2 B each][16 queues]. */
-template <typename ENTRY, int C, int S, bool COUNT_ONLY>
-__global__ __launch_bounds__ (DENSE_THREADS) void
-scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gdense, const uint4 *__restrict__ lds_image,
-                   uint32_t lds_image_bytes, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
-                   uint32_t *fill, const uint32_t *__restrict__ dstart) {
-  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
-  constexpr uint32_t TILE = WAVE * S * C;
-  constexpr int NB = C / 16;
-  constexpr bool CONT = EntryTraits<ENTRY>::CONT;
-
-  /* stage rows (+ hotfail): a straight 16-byte-per-lane copy of the prebuilt image */
-  {
-    uint4 *dst = reinterpret_cast<uint4 *> (smem);
-    for (uint32_t i = threadIdx.x; i < lds_image_bytes / 16; i += blockDim.x)
-      dst[i] = lds_image[i];
-  }
-  /* tiles are handed out dynamically inside the workgroup (its waves do not run at the same
-   * pace: a static split left the slowest wave of a block 11% behind the block's mean) */
-  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + (DENSE_THREADS / WAVE) * QCAP * 8);
-  if (threadIdx.x == 0)
-    *next_tile = 0;
-  __syncthreads ();
-
-  const uint32_t lane = threadIdx.x & (WAVE - 1);
-  const uint32_t wib = uniform (threadIdx.x / WAVE);
-  uint2 *queue = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
-  const uint32_t waves_per_block = blockDim.x / WAVE;
-  const uint32_t wave = blockIdx.x * waves_per_block + wib;
-  const uint32_t emit_from = A.emit_from, emit_end = A.n;
-  const uint32_t last_block = (A.n - 1) & ~15u; /* byte offset of the last 16-byte block with a valid byte */
-  /* Work split.  Block b owns the contiguous tiles [blk_begin, blk_begin + blk_tiles), handed to
-   * its waves through an LDS counter; once those are gone its waves draw single tiles from the
-   * pool of their class (16 consecutive blocks = 2 per XCD; one counter per class keeps the
-   * atomics per counter far below what one address sustains).  Blocks ran up to 6% apart. */
-  const uint32_t tiles_per_block = (A.static_end - A.range_begin + gridDim.x - 1) / gridDim.x;
-  const uint32_t blk_begin = A.range_begin + blockIdx.x * tiles_per_block;
-  const uint32_t blk_tiles = blk_begin >= A.static_end ? 0
-                             : (A.static_end - blk_begin < tiles_per_block ? A.static_end - blk_begin : tiles_per_block);
-  const uint32_t cls = blockIdx.x * POOL_CLASSES / gridDim.x;
-  const uint32_t cls_begin = A.static_end + cls * A.pool_class_tiles;
-  const uint32_t cls_tiles = cls_begin >= A.range_end ? 0
-                             : (A.range_end - cls_begin < A.pool_class_tiles ? A.range_end - cls_begin : A.pool_class_tiles);
-  unsigned int *const cls_ctr = A.pool_ctr + cls * POOL_CTR_STRIDE;
-  if (blockIdx.x == 0 && threadIdx.x < POOL_CLASSES)
-    A.pool_reset[threadIdx.x * POOL_CTR_STRIDE] = 0;
-  /* next tile of this wave, valid in lane 0 (A.range_end = none left); made uniform only where
-   * it is used, one tile later, so that the atomics' latency stays hidden */
-  auto grab_tile = [&] () -> uint32_t {
-    uint32_t t = A.range_end;
-    if (lane == 0) {
-      const uint32_t i = atomicAdd (next_tile, 1u);
-      if (i < blk_tiles)
-        t = blk_begin + i;
-      else if (cls_tiles) {
-        const uint32_t g = atomicAdd (cls_ctr, 1u);
-        if (g < cls_tiles)
-          t = cls_begin + g;
-      }
-    }
-    return t;
-  };
-  uint32_t cur = uniform (grab_tile ());
-  uint32_t nxt_raw = cur < A.range_end ? grab_tile () : A.range_end;
-
-  Walk<S> w;
-  w.qn = 0;
-  w.sticky = 0;
-  w.spill.region = items + (size_t)wave * region_items;
-  w.spill.capacity = items ? region_items : 0;
-  w.spill.fill = 0;
-  DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); const unsigned long long d_w0 = wall_clock64 (); unsigned long long d_text = 0, d_tiles = 0;)
-
-  static_assert (NB == 4, "the software pipeline below is written out for 4 blocks per chunk");
-  uint4 d[NB][S], post[S];
-  auto load_block = [&] (uint32_t p0, int k, int q) -> uint4 {
-    const uint32_t off = p0 + q * (WAVE * C) + 16 * k;
-    return *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
-  };
-  {
-    const uint32_t p0 = cur * TILE + lane * C;
-#pragma unroll
-    for (int q = 0; q < S; q++) {
-      d[0][q] = load_block (p0, 0, q);
-      d[1][q] = load_block (p0, 1, q);
-      d[2][q] = load_block (p0, 2, q);
-      d[3][q] = load_block (p0, 3, q);
-      post[q] = load_block (p0, NB, q);
-    }
-  }
-
-  while (cur < A.range_end) {
-    const uint32_t nxt = uniform (nxt_raw);
-    const uint32_t pos0 = cur * TILE + lane * C;  /* first byte of this lane's stream 0 */
-    const uint32_t npos0 = nxt * TILE + lane * C; /* the same lane's place in the wave's next tile */
-    cur = nxt;
-    if (nxt < A.range_end)
-      nxt_raw = grab_tile ();
-    DIAG (const unsigned long long d_tl = __builtin_readcyclecounter ();)
-#pragma unroll
-    for (int q = 0; q < S; q++)
-      w.s[q] = 0;
-    w.sticky = 0;
-    DIAG (asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); d_text += __builtin_readcyclecounter () - d_tl; d_tiles++;)
-    if (!CONT) {
-      /* sticky mode, ownership by END position.  Warm-up: wub 16-byte blocks before each chunk,
-       * walked from the root without reporting (matches ending there belong to the previous
-       * chunk's owner).  A chunk closer than that to the start of the segment starts from the
-       * root at its first in-range block instead. */
-      for (uint32_t b = K.wub; b >= 1; b--) {
-        uint4 pre[S];
-        const uint32_t back = 16u * b;
-#pragma unroll
-        for (int q = 0; q < S; q++) {
-          const uint32_t cs = pos0 + q * (WAVE * C);
-          const uint32_t off = cs >= back ? cs - back : 0;
-          pre[q] = *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
-        }
-        const StepAt at = { pos0 - back, 0, 0, PH_WARM };
-        dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, pre, at, lane);
-#pragma unroll
-        for (int q = 0; q < S; q++)
-          if (pos0 + q * (WAVE * C) < back)
-            w.s[q] = 0;
-      }
-    }
-    /* walk blocks 0 .. NB-2, refill their registers from the next tile, walk the last block,
-     * refill it.  (Refilling half and half re-touched every 128-byte line half a tile later, when
-     * part of them had already left L2: 1.37x the text in L2 misses.  Non-temporal loads were
-     * 1.55x slower for the same reason.) */
-    /* (written out block by block: a loop over k that the compiler declines to unroll would index
-     * the text registers dynamically and push them into scratch memory) */
-#define ACM_WALK_BLOCK(k)                                                                          \
-  {                                                                                                \
-    const StepAt at_ = { pos0 + 16 * (k), 0, 0, PH_MAIN };                                         \
-    dense_block<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, d[k], at_, lane); \
-  }
-#define ACM_REFILL_BLOCK(k)                                                                        \
-  _Pragma ("unroll") for (int q = 0; q < S; q++) d[k][q] = load_block (npos0, k, q);
-    ACM_WALK_BLOCK (0)
-    ACM_WALK_BLOCK (1)
-    ACM_WALK_BLOCK (2)
-    ACM_REFILL_BLOCK (0)
-    ACM_REFILL_BLOCK (1)
-    ACM_REFILL_BLOCK (2)
-    ACM_WALK_BLOCK (3)
-    ACM_REFILL_BLOCK (3)
-#undef ACM_WALK_BLOCK
-#undef ACM_REFILL_BLOCK
-    if (CONT) {
-      /* continuation mode, ownership by START position: run over into the following bytes until
-       * no lane's state is deeper than the number of bytes past its chunk (at most lmax - 1) */
-      bool done = false;
-      for (uint32_t b = 0; b < K.wub && !done; b++) {
-        if (b > 0) {
-#pragma unroll
-          for (int q = 0; q < S; q++)
-            post[q] = load_block (pos0, NB + b, q);
-        }
-#define ACM_RUN_BYTE(COMP, SH, J)                                                                  \
-  if (!done) {                                                                                     \
-    const uint32_t k_ = 16 * b + (J) + 1;                                                          \
-    const uint32_t live_from_ = dstart[k_ + 1 <= K.lmax ? k_ + 1 : K.lmax + 1];                    \
-    uint32_t b_[S];                                                                                \
-    _Pragma ("unroll") for (int q = 0; q < S; q++) b_[q] = (post[q].COMP >> (SH)) & 0xffu;         \
-    const StepAt at_ = { pos0 + C + 16 * b + (J), k_, live_from_, PH_RUN };                        \
-    dense_step<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, b_, at_, lane); \
-    bool live_ = false;                                                                            \
-    _Pragma ("unroll") for (int q = 0; q < S; q++) live_ |= w.s[q] >= live_from_;                  \
-    done = k_ + 1 >= K.lmax || __ballot (live_) == 0;                                              \
-  }
-#define ACM_RUN_WORD(COMP, J)                                                                      \
-  ACM_RUN_BYTE (COMP, 0, (J) + 0) ACM_RUN_BYTE (COMP, 8, (J) + 1) ACM_RUN_BYTE (COMP, 16, (J) + 2) ACM_RUN_BYTE (COMP, 24, (J) + 3)
-        ACM_RUN_WORD (x, 0) ACM_RUN_WORD (y, 4) ACM_RUN_WORD (z, 8) ACM_RUN_WORD (w, 12)
-#undef ACM_RUN_WORD
-#undef ACM_RUN_BYTE
-      }
-#pragma unroll
-      for (int q = 0; q < S; q++)
-        post[q] = load_block (npos0, NB, q);
-    }
-  }
-  if (w.qn)
-    queue_drain<CONT, COUNT_ONLY> (E, queue, w.qn, &w.spill, lane);
-  if (lane == 0 && fill)
-    fill[wave] = w.spill.fill;
-  DIAG (if (lane == 0 && wave < 8192) {
-    unsigned long long *o = g_acm_diag[wave];
-    o[0] = __builtin_readcyclecounter () - d_t0;
-    o[1] = wall_clock64 ();
-    o[7] = d_w0;
-    o[2] = w.spill.fill;
-    o[3] = w.d_slow_steps;
-    o[4] = w.d_slow_cycles;
-    o[5] = d_text;
-    o[6] = d_tiles;
-  })
-}
-
-/* ------------------------------------------------------------------ CSR kernel (any width) */
-__device__ __forceinline__ uint32_t
-csr_step (const CsrTables &T, uint32_t s, uint32_t c) {
-  for (;;) {
-    uint32_t b = T.row_ptr[s], e = T.row_ptr[s + 1];
-    if (e - b > 8) { /* rows are sorted by numeric symbol value */
-      while (e - b > 1) {
-        uint32_t m = (b + e) >> 1;
-        if (T.edge_sym[m] <= c)
-          b = m;
-        else
-          e = m;
-      }
-      if (T.edge_sym[b] == c)
-        return T.edge_next[b];
-    } else {
-      for (; b < e; b++)
-        if (T.edge_sym[b] == c)
-          return T.edge_next[b];
-    }
-    if (s == 0)
-      return 0;
-    s = T.fail[s];
-  }
-}
-
-/* One lane walks `chunk` symbols of [range_begin, range_end), restarting from the root lmax-1
- * symbols earlier (or at index 0 of the segment).  blockDim.x == 64: one wave per block. */
-template <typename SYM, bool COUNT_ONLY>
-__global__ __launch_bounds__ (WAVE) void
-scan_csr_kernel (CsrTables T, EmitCtx E, Launch A, uint32_t chunk) {
-  __shared__ uint2 queue[QCAP];
-  const uint32_t lane = threadIdx.x;
-  const SYM *text = reinterpret_cast<const SYM *> (A.text);
-  const uint32_t nchunks = (A.range_end - A.range_begin + chunk - 1) / chunk;
-  const uint32_t per_round = gridDim.x * WAVE;
-  const uint32_t rounds = (nchunks + per_round - 1) / per_round;
-  const uint32_t warm = T.lmax > 1 ? T.lmax - 1 : 0;
-  uint32_t qn = 0;
-  for (uint32_t r = 0; r < rounds; r++) {
-    const uint32_t ck = (r * gridDim.x + blockIdx.x) * WAVE + lane;
-    uint32_t begin = A.range_end, end = A.range_end, i = A.range_end;
-    if (ck < nchunks) {
-      begin = A.range_begin + ck * chunk;
-      end = A.range_end - begin > chunk ? begin + chunk : A.range_end;
-      i = begin > warm ? begin - warm : 0;
-    }
-    uint32_t s = 0;
-    /* all lanes iterate together so that the queue stays a wave-level structure */
-    const uint32_t steps_max = chunk + warm;
-    for (uint32_t k = 0; k < steps_max; k++, i++) {
-      bool hit = false;
-      if (i < end) {
-        s = csr_step (T, s, (uint32_t)text[i]);
-        hit = i >= begin && i >= A.emit_from && T.nb_outputs[s] != 0;
-      }
-      queue_push<false, COUNT_ONLY> (E, queue, qn, hit, i, s, lane);
-    }
-  }
-  flush_queue<false, COUNT_ONLY> (E, queue, qn);
-}
-
-/* ------------------------------------------------------------------ sparse kernel (2- and 4-byte symbols)
- * Large alphabets (token ids, UTF-16 units) make automata whose root has thousands of children
- * and whose other states have a handful: a random symbol usually leads from anywhere back to the
- * root or one of its children.  So:
- *   - the root row is a direct-indexed table by symbol value (in LDS when it fits: 128 KB);
- *   - every other state is a 32-byte record {fail, n_edges, edge_begin | sym0, next0, sym1, next1}:
- *     two 16-byte loads issued together resolve a state with at most two children whose
- *     failure state is the root -- anything else takes the general side (sparse_resolve);
- *   - a lane walks SPARSE_S independent chunks; its text comes 128 bytes (one cache line) at a
- *     time into registers, so that every line is fetched once, in one burst.
- * Ownership by END position: a chunk is warmed up over the lmax - 1 symbols before it. */
-constexpr int SPARSE_S = 2;
-constexpr int SPARSE_THREADS = 1024;
-struct SparseK {
-  const uint4 *srec;   /* 2 x uint4 per state */
-  const uint2 *sedge;  /* per goto edge, rows in ascending symbol order: {symbol, next | out flag << 31} */
-  const uint32_t *lut; /* root transitions by symbol value: next | out flag << 31 (0: stay at the root) */
-  uint32_t lut_size;   /* symbols >= lut_size bisect the root row instead */
-  uint32_t R;          /* 128-byte sub-chunks per lane-stream chunk */
-  uint32_t warm_subs;  /* sub-chunks walked before a chunk (>= lmax - 1 symbols) */
-  uint32_t warm_skip;  /* symbols at the start of the warm-up that need not be walked */
-  uint32_t queue_off;  /* LDS: [lut if staged][16 queues][tile counter] */
-};
-
-__device__ __forceinline__ uint32_t
-sparse_find (const SparseK &K, uint32_t begin, uint32_t ne, uint32_t c) {
-  uint32_t lo = begin, hi = begin + ne;
-  while (lo < hi) {
-    const uint32_t mid = lo + (hi - lo) / 2;
-    if (K.sedge[mid].x < c)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
-  if (lo < begin + ne) {
-    const uint2 e = K.sedge[lo];
-    if (e.x == c)
-      return e.y;
-  }
-  return NONE;
-}
-
-/* delta(t, c) in full: goto edge of t, else of f(t), ... else stay at the root (reference :167-192) */
-__device__ __noinline__ uint32_t
-sparse_resolve (const SparseK &K, uint32_t t, uint32_t c) {
-  for (;;) {
-    if (t == 0 && c < K.lut_size)
-      return K.lut[c];
-    const uint4 a = K.srec[2 * t];
-    const uint32_t ent = sparse_find (K, a.z, a.y, c);
-    if (ent != NONE)
-      return ent;
-    if (t == 0)
-      return 0;
-    t = a.x;
-  }
-}
-
-template <int I>
-__device__ __forceinline__ uint32_t
-word_of (const uint4 &v) {
-  if constexpr (I == 0)
-    return v.x;
-  else if constexpr (I == 1)
-    return v.y;
-  else if constexpr (I == 2)
-    return v.z;
-  else
-    return v.w;
-}
-
-template <typename SYM, bool LUT_LDS, bool COUNT_ONLY>
-__device__ __forceinline__ void
-sparse_step (const SparseK &K, const EmitCtx &E, uint2 *queue, uint32_t &qn, uint32_t (&s)[SPARSE_S],
-             const uint32_t (&tok)[SPARSE_S], const bool (&act)[SPARSE_S], const bool (&emit)[SPARSE_S],
-             const uint32_t (&pos)[SPARSE_S], uint32_t lane) {
-  constexpr int S = SPARSE_S;
-  uint32_t rootent[S], ent[S];
-  uint4 ra[S], rb[S];
-  bool slow[S], any_slow = false;
-#pragma unroll
-  for (int q = 0; q < S; q++) {
-    ra[q] = K.srec[2 * s[q]];
-    rb[q] = K.srec[2 * s[q] + 1];
-  }
-#pragma unroll
-  for (int q = 0; q < S; q++) {
-    const uint32_t c = tok[q];
-    rootent[q] = NONE;
-    if (c < K.lut_size) {
-      if (LUT_LDS) /* the table starts at LDS address 0 */
-        rootent[q] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (c * 4u);
-      else
-        rootent[q] = K.lut[c];
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < S; q++) {
-    const uint32_t c = tok[q];
-    uint32_t e = rootent[q];
-    bool need = false;
-    if (s[q] != 0) {
-      const uint32_t ne = ra[q].y;
-      if (ne >= 1 && rb[q].x == c)
-        e = rb[q].y;
-      else if (ne >= 2 && rb[q].z == c)
-        e = rb[q].w;
-      else if (ne > 2 || ra[q].x != 0)
-        need = true; /* more edges to look at, or a failure state other than the root */
-    }
-    if (e == NONE)
-      need = true; /* symbol beyond the root table */
-    ent[q] = e;
-    slow[q] = act[q] && need;
-    any_slow |= slow[q];
-  }
-  if (__ballot (any_slow)) {
-#pragma unroll
-    for (int q = 0; q < S; q++)
-      if (slow[q])
-        ent[q] = sparse_resolve (K, s[q], tok[q]);
-  }
-  bool hit[S], any_hit = false;
-#pragma unroll
-  for (int q = 0; q < S; q++) {
-    if (act[q])
-      s[q] = ent[q] & 0x7FFFFFFFu;
-    hit[q] = act[q] && emit[q] && (ent[q] >> 31);
-    any_hit |= hit[q];
-  }
-  if (__ballot (any_hit)) {
-#pragma unroll
-    for (int q = 0; q < S; q++)
-      queue_push<false, COUNT_ONLY> (E, queue, qn, hit[q], pos[q], s[q], lane);
-  }
-}
-
-/* compile-time loop over the symbols of a 128-byte sub-chunk (text registers statically indexed) */
-template <typename SYM, bool LUT_LDS, bool COUNT_ONLY, int J, int JN> struct SubLoop {
-  static __device__ __forceinline__ void
-  run (const SparseK &K, const EmitCtx &E, uint2 *queue, uint32_t &qn, uint32_t (&s)[SPARSE_S],
-       const uint4 (&d)[SPARSE_S][8], const uint32_t (&base)[SPARSE_S], const uint32_t (&lim)[SPARSE_S], uint32_t skip,
-       bool own, uint32_t lane) {
-    constexpr int PER = 16 / (int)sizeof (SYM);     /* symbols per 16-byte register group */
-    constexpr int PERW = 4 / (int)sizeof (SYM);     /* symbols per 32-bit word */
-    if ((uint32_t)J >= skip) {
-      uint32_t tok[SPARSE_S], pos[SPARSE_S];
-      bool act[SPARSE_S], emit[SPARSE_S];
-#pragma unroll
-      for (int q = 0; q < SPARSE_S; q++) {
-        const uint32_t w = word_of<(J % PER) / PERW> (d[q][J / PER]);
-        tok[q] = sizeof (SYM) == 4 ? w : (w >> (8 * sizeof (SYM) * (J % PERW))) & ((1u << (8 * (sizeof (SYM) & 3))) - 1u);
-        act[q] = (uint32_t)J < lim[q];
-        pos[q] = base[q] + J;
-        emit[q] = own && pos[q] >= E.emit_from;
-      }
-      sparse_step<SYM, LUT_LDS, COUNT_ONLY> (K, E, queue, qn, s, tok, act, emit, pos, lane);
-    }
-    SubLoop<SYM, LUT_LDS, COUNT_ONLY, J + 1, JN>::run (K, E, queue, qn, s, d, base, lim, skip, own, lane);
-  }
-};
-template <typename SYM, bool LUT_LDS, bool COUNT_ONLY, int JN> struct SubLoop<SYM, LUT_LDS, COUNT_ONLY, JN, JN> {
-  static __device__ __forceinline__ void
-  run (const SparseK &, const EmitCtx &, uint2 *, uint32_t &, uint32_t (&)[SPARSE_S], const uint4 (&)[SPARSE_S][8],
-       const uint32_t (&)[SPARSE_S], const uint32_t (&)[SPARSE_S], uint32_t, bool, uint32_t) {}
-};
-
-/* A.range_end = number of lane-stream chunks (K.R sub-chunks each) that cover the segment; tile t
- * = chunks [t * 64 * S, (t + 1) * 64 * S); blocks own contiguous tiles, handed to their waves
- * through an LDS counter. */
-template <typename SYM, bool LUT_LDS, bool COUNT_ONLY>
-__global__ __launch_bounds__ (SPARSE_THREADS) void
-scan_sparse_kernel (SparseK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text) {
-  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
-  constexpr int S = SPARSE_S;
-  constexpr uint32_t TPS = 128 / sizeof (SYM);
-  if (LUT_LDS) {
-    uint4 *dst = reinterpret_cast<uint4 *> (smem);
-    const uint4 *src = reinterpret_cast<const uint4 *> (K.lut);
-    for (uint32_t i = threadIdx.x; i < (K.lut_size + 3) / 4; i += blockDim.x)
-      dst[i] = src[i];
-  }
-  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + (SPARSE_THREADS / WAVE) * QCAP * 8);
-  if (threadIdx.x == 0)
-    *next_tile = 0;
-  __syncthreads ();
-
-  const uint32_t lane = threadIdx.x & (WAVE - 1);
-  const uint32_t wib = uniform (threadIdx.x / WAVE);
-  uint2 *queue = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
-  const uint32_t nchunks = A.range_end;
-  const uint32_t ntiles = (nchunks + WAVE * S - 1) / (WAVE * S);
-  const uint32_t tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
-  const uint32_t blk_begin = blockIdx.x * tiles_per_block;
-  const uint32_t blk_tiles = blk_begin >= ntiles ? 0 : (ntiles - blk_begin < tiles_per_block ? ntiles - blk_begin : tiles_per_block);
-  const uint32_t last_blk = (uint32_t)(((uint64_t)A.n * sizeof (SYM) - 1) / 16); /* last 16-byte block with a valid symbol */
-  const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
-  uint32_t qn = 0;
-
-  for (;;) {
-    uint32_t t = 0;
-    if (lane == 0)
-      t = atomicAdd (next_tile, 1u);
-    t = uniform (t);
-    if (t >= blk_tiles)
-      break;
-    const uint32_t tile = blk_begin + t;
-    uint32_t s[S];
-    int32_t sub_first[S];
-    bool ok[S];
-#pragma unroll
-    for (int q = 0; q < S; q++) {
-      const uint32_t c = tile * (WAVE * S) + q * WAVE + lane;
-      ok[q] = c < nchunks;
-      sub_first[q] = (int32_t)(c * K.R) - (int32_t)K.warm_subs;
-      s[q] = 0;
-    }
-    const uint32_t rounds = K.R + K.warm_subs;
-    for (uint32_t k = 0; k < rounds; k++) {
-      uint4 d[S][8];
-      uint32_t base[S], lim[S];
-#pragma unroll
-      for (int q = 0; q < S; q++) {
-        const int32_t u = sub_first[q] + (int32_t)k;
-        const bool valid = ok[q] && u >= 0;
-        const uint32_t ublk = valid ? (uint32_t)u * 8u : 0u;
-#pragma unroll
-        for (int v = 0; v < 8; v++)
-          d[q][v] = text16[ublk + v < last_blk ? ublk + v : last_blk];
-        base[q] = valid ? (uint32_t)u * TPS : 0u;
-        lim[q] = (valid && base[q] < A.n) ? (A.n - base[q] < TPS ? A.n - base[q] : TPS) : 0u;
-      }
-      const uint32_t skipped = k * TPS;
-      const uint32_t skip = k < K.warm_subs ? (K.warm_skip > skipped ? (K.warm_skip - skipped < TPS ? K.warm_skip - skipped : TPS) : 0u) : 0u;
-      const bool own = k >= K.warm_subs;
-      SubLoop<SYM, LUT_LDS, COUNT_ONLY, 0, (int)TPS>::run (K, E, queue, qn, s, d, base, lim, skip, own, lane);
-    }
-  }
-  flush_queue<false, COUNT_ONLY> (E, queue, qn);
-}
-
-/* ------------------------------------------------------------------ start-parallel kernel (2- and 4-byte symbols)
- * The same match set, computed without a state carried from symbol to symbol: a keyword occurs
- * at [i, i + L) iff the goto function alone (the trie, no failure transitions) leads from the root
- * through text[i .. i + L) to its terminal state.  With a large alphabet nearly every start dies
- * at once, so instead of one dependent table lookup per symbol (the sparse walk above waits
- * ~2.7 us of memory latency per step) every position is tested independently, in three sieves:
- *   1. one LDS lookup per symbol in the root table: child state | ALWAYS << 31 | SECOND << 30
- *      (SECOND: the symbol is the second symbol of some keyword).  A start survives if its
- *      symbol has a child and the next symbol has SECOND (config 5: 7% of the positions);
- *   2. the two smallest edge symbols of the child (8 bytes, a 69 KB table on config 5) against
- *      the next symbol -- the load is issued at once and looked at one group (1 KiB of text)
- *      later, so nobody waits for it.  Children that are keywords themselves or have more than
- *      two edges carry ALWAYS and pass both sieves unseen;
- *   3. what is left (config 5: 3 starts per 10,000 symbols) is queued per wave and walked down
- *      the trie 64 at a time (walk_starts); terminal states give records (end position, depth,
- *      keyword id).
- * The text is read the coalesced way: a wave takes 1 KiB groups, lane l the 16 bytes at 16 l,
- * four groups walked while the next four are in flight.  Every record belongs to the start
- * position that finds it: nothing is warmed up, nothing is found twice.  Worst case (every start
- * walks lmax symbols) is lmax dependent loads per symbol; ACM_GPU_SPARSE=walk selects the sparse
- * automaton walk instead. */
-struct StartsK {
-  const uint4 *srec;   /* 2 x uint4 per state: {-, n_edges, edge_begin, terminal} {sym0, next0, sym1, next1} */
-  const uint2 *sedge;  /* per goto edge, rows in ascending symbol order: {symbol, next} */
-  const uint2 *pairs;  /* states 0 .. root fan-out: the symbols of the first two edges (repeated / 0 when fewer) */
-  const uint32_t *lut; /* by symbol value: child | SECOND << 30 | ALWAYS << 31 */
-  uint32_t lut_size;
-  uint32_t R;          /* groups per tile, a multiple of 4 */
-  uint32_t queue_off;  /* LDS: [lut if staged][16 queues of 128][16 hit buffers of 64][tile counter] */
-  /* 4-gram kernel only: its records are laid out depth-first below depth 4 (a keyword's tail in
-   * consecutive records); an item names a depth-4 state by its breadth-first id, remap[id -
-   * remap_base] is its record, and word 0 of a record is the state's breadth-first id */
-  const uint32_t *remap;
-  uint32_t remap_base;
-};
-constexpr uint32_t ST_ALWAYS = 0x80000000u, ST_SECOND = 0x40000000u, ST_STATE = 0x3FFFFFFFu;
-
-/* Matches found by a wave collect in its LDS hit buffer as (end position, terminal state) and
- * leave up to 64 at a time for the wave's private region of the plan's item buffer in HBM (plain
- * coalesced stores); expand_hits_kernel turns the regions into records afterwards with one atomic
- * per block.  (One atomic on the record counter per find was 0.7 ms of serialised atomics on
- * config 5, one per 64 finds still 6 ms on config 3's 27 M matches: a single address sustains
- * ~90 atomics per microsecond.)  A full region falls back to records straight from here.
- * LDS per wave: [region pointer][capacity, fill][64 hits]. */
-constexpr uint32_t HITS_STRIDE = WAVE + 2; /* in 8-byte units */
-
-__device__ __forceinline__ void
-hits_init (uint2 *hits, uint2 *region, uint32_t capacity, uint32_t lane) {
-  if (lane == 0) {
-    const uint64_t a = reinterpret_cast<uint64_t> (region);
-    hits[-2] = make_uint2 ((uint32_t)a, (uint32_t)(a >> 32));
-    hits[-1] = make_uint2 (region ? capacity : 0u, 0u);
-  }
-}
-
-__device__ __forceinline__ void
-flush_hits (const EmitCtx &E, uint2 *hits, uint32_t n, uint32_t lane) {
-  const uint2 rp = hits[-2], cf = hits[-1];
-  if (cf.y + n <= cf.x) {
-    uint2 *region = reinterpret_cast<uint2 *> (((uint64_t)rp.y << 32) | rp.x);
-    if (lane < n)
-      region[cf.y + lane] = hits[lane];
-    if (lane == 0)
-      hits[-1] = make_uint2 (cf.x, cf.y + n);
-    return;
-  }
-  unsigned long long base = 0;
-  if (lane == 0)
-    base = atomicAdd (E.count, (unsigned long long)n);
-  base = ((unsigned long long)__shfl ((uint32_t)(base >> 32), 0, WAVE) << 32) | __shfl ((uint32_t)base, 0, WAVE);
-  if (lane < n && base + lane < E.capacity) {
-    const uint2 h = hits[lane];
-    const uint4 oi = E.oinfo[h.y]; /* terminal state: its first output is its own keyword */
-    const uint64_t gp = E.pos_base + h.x;
-    *reinterpret_cast<uint4 *> (&E.records[base + lane]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), oi.z, oi.w);
-  }
-}
-
-/* one record per parked hit; a block takes REGIONS consecutive regions and reserves their
- * records with one atomic; it zeroes the fill counters it consumed */
-template <int THREADS, int REGIONS>
-__global__ __launch_bounds__ (THREADS) void
-expand_hits_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint32_t *fill, uint32_t n_regions) {
-  __shared__ uint32_t s_off[REGIONS + 1];
-  __shared__ unsigned long long s_base;
-  const uint32_t tid = threadIdx.x;
-  const uint32_t r0 = blockIdx.x * REGIONS;
-  if (tid < REGIONS) {
-    const uint32_t r = r0 + tid;
-    s_off[tid + 1] = r < n_regions ? fill[r] : 0;
-    if (r < n_regions)
-      fill[r] = 0;
-  }
-  __syncthreads ();
-  if (tid == 0) {
-    uint32_t acc = 0;
-    for (int r = 0; r < REGIONS; r++) {
-      const uint32_t v = s_off[r + 1];
-      s_off[r] = acc;
-      acc += v;
-    }
-    s_off[REGIONS] = acc;
-    s_base = acc ? atomicAdd (E.count, (unsigned long long)acc) : 0ull;
-  }
-  __syncthreads ();
-  const uint32_t total = s_off[REGIONS];
-  const unsigned long long base = s_base;
-  for (uint32_t i = tid; i < total; i += THREADS) {
-    uint32_t r = 0;
-#pragma unroll
-    for (int k = 1; k < REGIONS; k++)
-      r += s_off[k] <= i ? 1u : 0u;
-    const uint2 h = items[(size_t)(r0 + r) * region_items + (i - s_off[r])];
-    if (base + i < E.capacity) {
-      const uint4 oi = E.oinfo[h.y];
-      const uint64_t gp = E.pos_base + h.x;
-      *reinterpret_cast<uint4 *> (&E.records[base + i]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), oi.z, oi.w);
-    }
-  }
-}
-
-/* tally: this lane's finds (count-only mode; summed over the wave at the end of the kernel) or
- * the fill of the hit buffer (record mode, wave-uniform) */
-template <bool COUNT_ONLY>
-__device__ __forceinline__ void
-emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t lane, uint2 *hits, unsigned long long &tally) {
-  if (COUNT_ONLY) {
-    tally += hit ? 1u : 0u;
-    return;
-  }
-  const uint64_t m = __ballot (hit);
-  if (m) {
-    const uint32_t total = (uint32_t)__popcll (m);
-    uint32_t hn = (uint32_t)tally;
-    if (hn + total > WAVE) {
-      flush_hits (E, hits, hn, lane);
-      hn = 0;
-    }
-    if (hit)
-      hits[hn + (uint32_t)__popcll (m & ((1ull << lane) - 1))] = make_uint2 (p, st);
-    tally = hn + total;
-  }
-}
-
-/* third sieve: the newest n_items (<= 64) of a wave's queue, item = (position p of the last
- * symbol read, state reached | flags).  ONE level per call: report the state if it is terminal,
- * look its goto edge on text[p + 1] up, and put the starts that go on back into the queue -- the
- * few long walks (a planted keyword of 12 symbols) then travel in full batches with everybody
- * else's instead of holding 63 idle lanes for 8 rounds of memory latency each.
- * Returns (new queue fill << 32) | tally.
- * (The structs come by pointer to copies the caller makes on the spot: taking the address of the
- * kernel's own K and E would move them from scalar registers to scratch memory for the whole
- * kernel -- measured 2x on the main loop.) */
-constexpr uint32_t WALK_CTX_K = 128, WALK_CTX_BYTES = 16 + 128 + 256; /* LDS after the tile counter: StartsK, EmitCtx */
-static_assert (sizeof (StartsK) <= WALK_CTX_K && sizeof (EmitCtx) <= 256, "walk context does not fit its LDS slot");
-constexpr uint32_t WI_REPORTED = 0x80000000u; /* what ends in this state has been reported by the caller */
-constexpr uint32_t WI_RECORD = 0x40000000u;   /* 4-gram kernel: the index is a record index already (StartsK::remap) */
-template <typename SYM, bool COUNT_ONLY, bool GRAM = false>
-__device__ __noinline__ unsigned long long
-walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue, uint32_t qn, uint32_t n_items, uint2 *hits,
-             unsigned long long counted) {
-  const StartsK &K = *Kp;
-  const EmitCtx &E = *Ep;
-  const uint32_t lane = lane_id ();
-  const uint32_t base = qn - n_items;
-  const bool alive = lane < n_items;
-  const uint2 it = alive ? queue[base + lane] : make_uint2 (0, 0);
-  const uint32_t p = it.x;
-  uint32_t st = it.y & ST_STATE;
-  if (GRAM && !(it.y & WI_RECORD))
-    st = alive ? K.remap[st - K.remap_base] : 0u;
-  const uint4 ra = K.srec[2 * st], rb = K.srec[2 * st + 1];
-  const bool more = alive && p + 1 < E.n;
-  const uint32_t c1 = more ? (uint32_t)text[p + 1] : 0u;
-  emit_terminals<COUNT_ONLY> (E, alive && !(it.y & WI_REPORTED) && ra.w != 0 && p >= E.emit_from, p, GRAM ? ra.x : st, lane, hits,
-                              counted);
-  uint32_t nx = NONE;
-  if (more) {
-    const uint32_t ne = ra.y;
-    if (ne >= 1 && rb.x == c1)
-      nx = rb.y;
-    else if (ne >= 2 && rb.z == c1)
-      nx = rb.w;
-    else if (ne > 2) {
-      uint32_t lo = ra.z, hi = ra.z + ne;
-      while (lo < hi) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (K.sedge[mid].x < c1)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
-      if (lo < ra.z + ne) {
-        const uint2 e = K.sedge[lo];
-        if (e.x == c1)
-          nx = e.y;
-      }
-    }
-  }
-  const bool go = nx != NONE;
-  const uint64_t m = __ballot (go);
-  if (go)
-    queue[base + (uint32_t)__popcll (m & ((1ull << lane) - 1))] = make_uint2 (p + 1, nx | (GRAM ? WI_RECORD : 0u));
-  const uint32_t fill = base + (uint32_t)__popcll (m);
-  if (COUNT_ONLY)
-    return ((unsigned long long)fill << 32) | (uint32_t)counted;
-  /* record mode: the tally is the fill of the hit buffer, one value for the wave */
-  return ((unsigned long long)fill << 32) | uniform ((uint32_t)counted);
-}
-
-template <bool LUT_LDS>
-__device__ __forceinline__ uint32_t
-starts_root (const StartsK &K, uint32_t c) {
-  if (c < K.lut_size) {
-    if (LUT_LDS)
-      return *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (c * 4u);
-    return K.lut[c];
-  }
-  /* beyond the table: bisect the root row; no sieve can be applied, let everything pass */
-  const uint4 a = K.srec[0];
-  uint32_t lo = a.z, hi = a.z + a.y;
-  while (lo < hi) {
-    const uint32_t mid = lo + (hi - lo) / 2;
-    if (K.sedge[mid].x < c)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
-  if (lo < a.z + a.y) {
-    const uint2 e = K.sedge[lo];
-    if (e.x == c)
-      return e.y | ST_SECOND | ST_ALWAYS;
-  }
-  return ST_SECOND;
-}
-
-/* a start between the first and the second sieve */
-struct PendingStart {
-  uint2 pair;     /* the child's first two edge symbols (load in flight) */
-  uint32_t ntok;  /* the symbol after the start */
-  uint32_t child; /* root-table entry of the start's symbol; 0 = none pending */
-  uint32_t pos;
-};
-
-template <typename SYM, bool LUT_LDS, bool COUNT_ONLY>
-__global__ __launch_bounds__ (SPARSE_THREADS) void
-scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text8, uint2 *items, uint32_t region_items,
-                    uint32_t *fill) {
-  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
-  constexpr uint32_t PER = 16 / sizeof (SYM);  /* symbols per lane per group */
-  constexpr uint32_t PERW = 4 / sizeof (SYM);  /* symbols per 32-bit word */
-  constexpr uint32_t GROUP = WAVE * PER;
-  constexpr uint32_t SYM_MASK = sizeof (SYM) == 4 ? 0xFFFFFFFFu : (1u << (8 * (sizeof (SYM) & 3))) - 1u;
-  if (LUT_LDS) {
-    uint4 *dst = reinterpret_cast<uint4 *> (smem);
-    const uint4 *src = reinterpret_cast<const uint4 *> (K.lut);
-    for (uint32_t i = threadIdx.x; i < (K.lut_size + 3) / 4; i += blockDim.x)
-      dst[i] = src[i];
-  }
-  constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
-  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (QCAP + HITS_STRIDE) * 8);
-  /* what walk_starts needs of K and E, once per block in LDS: handing it the kernel's own
-   * structs by address would move them from scalar registers to scratch for the whole kernel,
-   * and a copy per call is 13 KB of scratch traffic per wave and call */
-  StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4);
-  EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
-  if (threadIdx.x == 0) {
-    *next_tile = 0;
-    *Ks = K;
-    *Es = E;
-  }
-  __syncthreads ();
-
-  const uint32_t lane = threadIdx.x & (WAVE - 1);
-  const uint32_t wib = uniform (threadIdx.x / WAVE);
-  uint2 *queue = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
-  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * HITS_STRIDE + 2;
-  const uint32_t wave_id = blockIdx.x * WAVES + wib;
-  hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
-  const SYM *text = reinterpret_cast<const SYM *> (text8);
-  const uint4 *text16 = reinterpret_cast<const uint4 *> (text8);
-  /* block b takes the tiles b, b + gridDim.x, ... (match density is rarely even along a text:
-   * contiguous shares left two blocks of config 3 working 1 ms after all others had finished),
-   * handed to its waves through the LDS counter */
-  const uint32_t ntiles = A.range_end - A.range_begin;
-  const uint32_t blk_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-  const uint32_t last_blk = (uint32_t)(((uint64_t)A.n * sizeof (SYM) - 1) / 16);
-  uint32_t qn = 0;
-  unsigned long long counted = 0;
-  DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_cands = 0, d_deep = 0, d_tiles = 0;)
-  PendingStart pend[4][PERW];
-#pragma unroll
-  for (int w = 0; w < 4; w++)
-#pragma unroll
-    for (uint32_t i = 0; i < PERW; i++)
-      pend[w][i].child = 0;
-
-  auto load_group = [&] (uint32_t g) -> uint4 {
-    const uint32_t blk = g * WAVE + lane;
-#ifdef ST_EXP_NT
-    typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
-    const v4u v = __builtin_nontemporal_load (reinterpret_cast<const v4u *> (&text16[blk < last_blk ? blk : last_blk]));
-    return make_uint4 (v.x, v.y, v.z, v.w);
-#else
-    return text16[blk < last_blk ? blk : last_blk];
-#endif
-  };
-  /* second sieve on a start whose pair has arrived; survivors go to the wave's queue */
-  auto resolve = [&] (PendingStart &P) {
-    const bool deep = P.child != 0 && ((P.child & ST_ALWAYS) || P.pair.x == P.ntok || P.pair.y == P.ntok);
-    const uint64_t m = __ballot (deep);
-    if (m) {
-      if (deep)
-        queue[qn + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (P.pos, P.child & ST_STATE);
-      qn = uniform (qn + (uint32_t)__popcll (m));
-      while (qn >= WAVE) {
-        DIAG (const unsigned long long d_c0 = __builtin_readcyclecounter ();)
-        {
-          const unsigned long long r = walk_starts<SYM, COUNT_ONLY> (Ks, Es, text, queue, qn, WAVE, hits, counted);
-          qn = uniform ((uint32_t)(r >> 32));
-          counted = (uint32_t)r;
-        }
-        DIAG (d_walk += __builtin_readcyclecounter () - d_c0; d_calls++;)
-      }
-    }
-    DIAG (d_cands += __popcll (__ballot (P.child != 0)); d_deep += __popcll (m);)
-    P.child = 0;
-  };
-  /* first sieve on the start at position p: e0 = entry of its symbol, e1 = entry of the next
-   * symbol (0 when there is none), ntok = the next symbol */
-  auto sieve = [&] (PendingStart &P, uint32_t e0, uint32_t e1, uint32_t ntok, uint32_t p) {
-    resolve (P); /* the start that used this slot one group ago */
-    /* (straight-line: every lane loads, the ones without a start pairs[0]; a load under a branch
-     * would make the compiler wait for everything in flight, prefetched text included) */
-    const bool cand = (e0 & ST_STATE) != 0 && ((e0 & ST_ALWAYS) || (e1 & ST_SECOND));
-    P.child = cand ? e0 : 0u;
-    P.pair = K.pairs[P.child & ST_STATE];
-    P.ntok = ntok;
-    P.pos = p;
-  };
-  /* one group: `cur` = this lane's 16 bytes, next_x = word 0 of every lane of the following group */
-  auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t g) {
-    const uint32_t pos0 = g * GROUP + lane * PER; /* position of this lane's first symbol */
-    /* word 0 of the next lane (of the next group for lane 63): holds the successor of this lane's last symbol */
-    uint32_t after = __shfl_down (cur.x, 1, WAVE);
-    const uint32_t after_group = uniform (next_x);
-    if (lane == WAVE - 1)
-      after = after_group;
-    const uint32_t words[5] = { cur.x, cur.y, cur.z, cur.w, after };
-    uint32_t e_first = pos0 < A.n ? starts_root<LUT_LDS> (K, cur.x & SYM_MASK) : 0u;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      const uint32_t p = pos0 + w * PERW;
-      const uint32_t ntok_word = words[w + 1] & SYM_MASK;
-      const uint32_t e_next = p + PERW < A.n ? starts_root<LUT_LDS> (K, ntok_word) : 0u;
-      if (PERW == 2) {
-        const uint32_t mid = words[w] >> 16;
-        const uint32_t e_mid = p + 1 < A.n ? starts_root<LUT_LDS> (K, mid) : 0u;
-        sieve (pend[w][0], e_first, e_mid, mid, p);
-        sieve (pend[w][PERW - 1], e_mid, e_next, ntok_word, p + 1);
-      } else
-        sieve (pend[w][0], e_first, e_next, ntok_word, p);
-      e_first = e_next;
-    }
-  };
-
-  for (;;) {
-    uint32_t t = 0;
-    if (lane == 0)
-      t = atomicAdd (next_tile, 1u);
-    t = uniform (t);
-    if (t >= blk_tiles)
-      break;
-    DIAG (d_tiles++;)
-    const uint32_t g0 = (A.range_begin + t * gridDim.x + blockIdx.x) * K.R;
-    uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
-    for (uint32_t k = 0; k < K.R; k += 4) {
-      const uint32_t g = g0 + k;
-      const uint4 n0 = load_group (g + 4), n1 = load_group (g + 5), n2 = load_group (g + 6), n3 = load_group (g + 7);
-      walk_group (c0, c1.x, g);
-      walk_group (c1, c2.x, g + 1);
-      walk_group (c2, c3.x, g + 2);
-      walk_group (c3, n0.x, g + 3);
-      c0 = n0;
-      c1 = n1;
-      c2 = n2;
-      c3 = n3;
-    }
-  }
-#pragma unroll
-  for (int w = 0; w < 4; w++)
-#pragma unroll
-    for (uint32_t i = 0; i < PERW; i++)
-      resolve (pend[w][i]);
-  while (qn) {
-    const unsigned long long r = walk_starts<SYM, COUNT_ONLY> (Ks, Es, text, queue, qn, qn < WAVE ? qn : WAVE, hits, counted);
-    qn = uniform ((uint32_t)(r >> 32));
-    counted = (uint32_t)r;
-  }
-  if (COUNT_ONLY) {
-    const uint32_t incl = wave_incl_scan ((uint32_t)counted); /* a lane finds far fewer than 2^32 / 64 */
-    const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
-    if (lane == 0 && total)
-      atomicAdd (E.count, (unsigned long long)total);
-  } else {
-    if (counted)
-      flush_hits (E, hits, (uint32_t)counted, lane);
-    if (lane == 0 && fill)
-      fill[wave_id] = hits[-1].y;
-  }
-  DIAG (if (lane == 0) {
-    const uint32_t wave = blockIdx.x * (SPARSE_THREADS / WAVE) + wib;
-    if (wave < 8192) {
-      unsigned long long *o = g_acm_diag[wave];
-      o[0] = __builtin_readcyclecounter () - d_t0;
-      o[1] = d_walk;
-      o[2] = d_calls;
-      o[3] = d_cands;
-      o[4] = d_deep;
-      o[5] = d_tiles;
-    }
-  })
-}
-
-/* ------------------------------------------------------------------ 4-gram sieve kernel (byte alphabets, big dictionaries)
- * Dictionaries whose automaton does not fit the LDS scheme of the dense kernel (more than 32,768
- * states: config 3 has 508,339) make every step of a carried-state walk a dependent gather into
- * tens of megabytes of rows (99 GB/s).  When every keyword has at least 4 symbols and the
- * alphabet is small (width W = span + 1 <= 30), the start-parallel idea works for bytes too:
- *   1. LDS holds one bit per possible 4-gram over the W classes (W^4 bits: 66 KB for a-z): "some
- *      keyword starts with it".  Every position is tested with one ds_read_b32 on a rolling
- *      4-gram index (config 3: 19.6% pass);
- *   2. the survivors are queued per wave as (position, 4-gram index, class of the 5th symbol)
- *      and checked 64 at a time against an 8-byte record per 4-gram: {terminal bit | 26-bit mask
- *      of the depth-4 state's children, its state id}; the gather of batch k is in flight
- *      while the scan fills batch k + 1 (config 3: 3.2% of the positions pass -- all real:
- *      a keyword of length 4 ends there or a 5-symbol prefix of a keyword does);
- *   3. those go to walk_starts (shared with the start-parallel kernel) at the depth-4 state.
- * Text is read as in the start-parallel kernel (1 KiB groups, 16 bytes per lane, four groups in
- * flight). */
-struct GramK {
-  const uint2 *g4rec;     /* [W^4] {children mask | terminal << 31, state id of the depth-4 node (0: none)} */
-  const uint32_t *g4bits; /* [g4words] one bit per 4-gram, staged in LDS */
-  const uint4 *srec;      /* trie records of the states of depth >= 4, depth-first order (see StartsK::remap) */
-  const uint2 *sedge;
-  const uint32_t *g4gid;  /* [states of depth 4] record index of each depth-4 state */
-  uint32_t d4_begin;      /* breadth-first id of the first depth-4 state */
-  uint32_t g4words;
-  uint32_t W, lo, span, W4; /* class = min (byte - lo, span); W = span + 1 */
-  uint32_t R;             /* groups per tile */
-  uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
-};
-
-template <bool COUNT_ONLY>
-__global__ __launch_bounds__ (SPARSE_THREADS) void
-scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
-                  uint32_t *fill) {
-  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
-  constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
-  constexpr uint32_t GROUP = WAVE * 16;
-  {
-    uint4 *dst = reinterpret_cast<uint4 *> (smem);
-    const uint4 *src = reinterpret_cast<const uint4 *> (K.g4bits);
-    for (uint32_t i = threadIdx.x; i < (K.g4words + 3) / 4; i += blockDim.x)
-      dst[i] = src[i];
-  }
-  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (2 * QCAP + HITS_STRIDE) * 8);
-  StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4); /* see scan_starts_kernel */
-  EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
-  if (threadIdx.x == 0) {
-    *next_tile = 0;
-    StartsK Kc{};
-    Kc.srec = K.srec;
-    Kc.sedge = K.sedge;
-    Kc.remap = K.g4gid;
-    Kc.remap_base = K.d4_begin;
-    *Ks = Kc;
-    *Es = E;
-  }
-  __syncthreads ();
-
-  const uint32_t lane = threadIdx.x & (WAVE - 1);
-  const uint32_t wib = uniform (threadIdx.x / WAVE);
-  uint2 *q1 = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
-  uint2 *q2 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * QCAP;
-  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + 2 * WAVES * QCAP + wib * HITS_STRIDE + 2;
-  const uint32_t wave_id = blockIdx.x * WAVES + wib;
-  hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
-  const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
-  /* block b takes the tiles b, b + gridDim.x, ... (match density is rarely even along a text:
-   * contiguous shares left two blocks of config 3 working 1 ms after all others had finished),
-   * handed to its waves through the LDS counter */
-  const uint32_t ntiles = A.range_end - A.range_begin;
-  const uint32_t blk_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-  const uint32_t last_blk = (A.n - 1) / 16;
-  uint32_t qn1 = 0, qn2 = 0;
-  unsigned long long counted = 0;
-  /* batches of the first queue whose records are in flight: a pipeline of GRAM_DEPTH batches
-   * (the gather of a batch has the time it takes the scan to fill that many more before it is
-   * looked at: one batch ahead left the L2 / MALL latency exposed) */
-  constexpr int GRAM_DEPTH = 3;
-  DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_items = 0, d_b1 = 0, d_cons = 0, d_tiles = 0;)
-  uint2 pend_item[GRAM_DEPTH], pend_rec[GRAM_DEPTH];
-  uint32_t pend_n[GRAM_DEPTH]; /* wave-uniform: items in each pending batch, [0] the oldest */
-#pragma unroll
-  for (int d = 0; d < GRAM_DEPTH; d++) {
-    pend_item[d] = make_uint2 (0, 0);
-    pend_rec[d] = make_uint2 (0, 0);
-    pend_n[d] = 0;
-  }
-
-  auto load_group = [&] (uint32_t g) -> uint4 {
-    const uint32_t blk = g * WAVE + lane;
-    return text16[blk < last_blk ? blk : last_blk];
-  };
-  auto walk_batch = [&] (uint32_t n_items) {
-    DIAG (const unsigned long long d_c0 = __builtin_readcyclecounter ();)
-    const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, true> (Ks, Es, text, q2, qn2, n_items, hits, counted);
-    qn2 = uniform ((uint32_t)(r >> 32));
-    counted = (uint32_t)r;
-    DIAG (d_walk += __builtin_readcyclecounter () - d_c0; d_calls++; d_items += n_items;)
-  };
-  /* second sieve on the oldest pending batch: terminal, or the 5th symbol is an edge of the
-   * depth-4 state; then the pipeline moves up */
-  auto consume_oldest = [&] () {
-    if (pend_n[0]) {
-      const uint32_t c4 = pend_item[0].y >> 20;
-      const bool valid = lane < pend_n[0];
-      /* a keyword of length 4 ends here: reported at once, its record needs nothing but the
-       * state id (the trie records of the 508,339 states are 16 MB of HBM: not worth a visit) */
-      const bool term = valid && (pend_rec[0].x >> 31) && pend_item[0].x + 3 >= E.emit_from;
-      emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, pend_rec[0].y, lane, hits, counted);
-      if (!COUNT_ONLY)
-        counted = uniform ((uint32_t)counted);
-      const bool pass = valid && ((pend_rec[0].x >> c4) & 1u);
-      const uint64_t m = __ballot (pass);
-      if (m) {
-        if (pass)
-          q2[qn2 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pend_item[0].x + 3, pend_rec[0].y | WI_REPORTED);
-        qn2 = uniform (qn2 + (uint32_t)__popcll (m));
-        while (qn2 >= WAVE)
-          walk_batch (WAVE);
-      }
-    }
-#pragma unroll
-    for (int d = 0; d + 1 < GRAM_DEPTH; d++) {
-      pend_item[d] = pend_item[d + 1];
-      pend_rec[d] = pend_rec[d + 1];
-      pend_n[d] = pend_n[d + 1];
-    }
-    pend_n[GRAM_DEPTH - 1] = 0;
-  };
-  /* takes the newest n items of the first queue and sends for their records (the last pipeline
-   * slot is free: consume_oldest ran just before) */
-  auto issue_batch = [&] (uint32_t n_items) {
-    qn1 -= n_items;
-    pend_item[GRAM_DEPTH - 1] = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
-#ifdef GRAM_EXP_NOGATHER
-    pend_rec[GRAM_DEPTH - 1] = make_uint2 (pend_item[GRAM_DEPTH - 1].y >> 3, 1);
-#else
-    pend_rec[GRAM_DEPTH - 1] = K.g4rec[pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu];
-#endif
-    pend_n[GRAM_DEPTH - 1] = n_items;
-  };
-
-  /* one group: cur = this lane's 16 bytes, next_x = the first 4 bytes of every lane of the next group */
-  auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t g) {
-    uint32_t after = __shfl_down (cur.x, 1, WAVE);
-    const uint32_t after_group = uniform (next_x);
-    if (lane == WAVE - 1)
-      after = after_group;
-    const uint32_t pos0 = g * GROUP + lane * 16;
-    const uint32_t w[5] = { cur.x, cur.y, cur.z, cur.w, after };
-    uint32_t c[20];
-#pragma unroll
-    for (int j = 0; j < 20; j++) {
-      const uint32_t b = (w[j / 4] >> (8 * (j % 4))) & 0xFFu;
-      c[j] = min (b - K.lo, K.span);
-    }
-    /* symbols past the end of the segment count as outside the alphabet (only the last groups) */
-    if (pos0 + 20 > A.n) {
-#pragma unroll
-      for (int j = 0; j < 20; j++)
-        if (pos0 + j >= A.n)
-          c[j] = K.span;
-    }
-    uint32_t idx = ((c[0] * K.W + c[1]) * K.W + c[2]) * K.W + c[3];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint32_t word = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
-      const bool push = (word >> (idx & 31u)) & 1u;
-      const uint64_t m = __ballot (push);
-      if (m) {
-        if (push)
-          q1[qn1 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos0 + j, idx | (c[j + 4] << 20));
-        qn1 = uniform (qn1 + (uint32_t)__popcll (m));
-        if (qn1 >= WAVE) {
-          DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)
-          consume_oldest ();
-          issue_batch (WAVE);
-          DIAG (d_cons += __builtin_readcyclecounter () - d_c1; d_b1++;)
-        }
-      }
-      idx = idx * K.W + c[j + 4] - c[j] * K.W4;
-    }
-  };
-
-  for (;;) {
-    uint32_t t = 0;
-    if (lane == 0)
-      t = atomicAdd (next_tile, 1u);
-    t = uniform (t);
-    if (t >= blk_tiles)
-      break;
-    DIAG (d_tiles++;)
-    const uint32_t g0 = (A.range_begin + t * gridDim.x + blockIdx.x) * K.R;
-    uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
-    for (uint32_t k = 0; k < K.R; k++) {
-      const uint4 n3 = load_group (g0 + k + 4);
-      walk_group (c0, c1.x, g0 + k);
-      c0 = c1;
-      c1 = c2;
-      c2 = c3;
-      c3 = n3;
-    }
-  }
-  if (qn1) {
-    consume_oldest ();
-    issue_batch (qn1);
-  }
-#pragma unroll
-  for (int d = 0; d < GRAM_DEPTH; d++)
-    consume_oldest ();
-  while (qn2)
-    walk_batch (qn2 < WAVE ? qn2 : WAVE);
-  if (COUNT_ONLY) {
-    const uint32_t incl = wave_incl_scan ((uint32_t)counted);
-    const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
-    if (lane == 0 && total)
-      atomicAdd (E.count, (unsigned long long)total);
-  } else {
-    if (counted)
-      flush_hits (E, hits, (uint32_t)counted, lane);
-    if (lane == 0 && fill)
-      fill[wave_id] = hits[-1].y;
-  }
-  DIAG (if (lane == 0 && wave_id < 8192) {
-    unsigned long long *o = g_acm_diag[wave_id];
-    o[0] = __builtin_readcyclecounter () - d_t0;
-    o[1] = d_walk;
-    o[2] = d_calls;
-    o[3] = d_items;
-    o[4] = d_b1;
-    o[5] = d_cons;
-    o[6] = wall_clock64 ();
-    o[7] = d_tiles;
-  })
-}
-
-/* ------------------------------------------------------------------ comparator classes
- * Plans of machines flattened over comparator classes (acm_flatten_classes) map the text to
- * class ids first: one table of 65,536 16-bit entries in LDS serves both symbol sizes -- 2-byte
- * symbols index it directly, bytes go through it two at a time ((class(hi) << 8) | class(lo)), so
- * either way it is one ds_read_u16 per two bytes of text. */
-__global__ __launch_bounds__ (1024) void
-classmap_kernel (const uint4 *__restrict__ in, uint4 *__restrict__ out, uint64_t n_blocks16, const uint16_t *__restrict__ lut) {
-  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
-  {
-    uint4 *dst = reinterpret_cast<uint4 *> (smem);
-    const uint4 *src = reinterpret_cast<const uint4 *> (lut);
-    for (uint32_t i = threadIdx.x; i < 65536 * 2 / 16; i += blockDim.x)
-      dst[i] = src[i];
-  }
-  __syncthreads ();
-  const uint16_t *l = reinterpret_cast<const uint16_t *> (smem);
-  auto map2 = [&] (uint32_t w) -> uint32_t { return (uint32_t)l[w & 0xFFFFu] | ((uint32_t)l[w >> 16] << 16); };
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks16; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint4 v = in[i];
-    out[i] = make_uint4 (map2 (v.x), map2 (v.y), map2 (v.z), map2 (v.w));
-  }
-}
-
-/* element-wise form for the last bytes of a buffer and for buffers that are not 16-byte aligned */
-template <typename SYM>
-__global__ void
-classmap_tail_kernel (const SYM *__restrict__ in, SYM *__restrict__ out, uint64_t begin, uint64_t n, const uint16_t *__restrict__ lut) {
-  for (uint64_t i = begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    out[i] = (SYM)lut[in[i]]; /* a byte v indexes entry (0 << 8) | v: class(v) in its low byte */
-}
-
-/* ------------------------------------------------------------------ incremental updates
- * word patches for the tables of the start-parallel kernel: {table, index, value, -} */
-struct PatchTables {
-  uint32_t *t[5];
-};
-__global__ void
-patch_kernel (PatchTables T, const uint4 *__restrict__ patches, uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const uint4 q = patches[i];
-    T.t[q.x][q.y] = q.z;
-  }
-}
-
-/* ------------------------------------------------------------------ sort keys */
-__global__ void
-make_keys_kernel (const ACMRecord *rec, uint64_t n, uint32_t len_bits, uint64_t *keys) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const uint64_t lmask = (1ull << len_bits) - 1;
-    keys[i] = (rec[i].end_pos << len_bits) | (lmask - (rec[i].length & lmask));
-  }
-}
-
-struct Rec16 {
-  uint64_t a, b;
-};
-
-/* ------------------------------------------------------------------ synthetic text */
-__device__ __forceinline__ uint64_t
-splitmix64 (uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
-
-template <typename SYM>
-__global__ void
-synth_text_kernel (SYM *text, uint64_t n, uint64_t gbegin, uint32_t vocab, const SYM *kw, const uint32_t *kw_off, uint32_t n_kw) {
-  constexpr uint64_t P = 4096;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; li < n; li += stride) {
-    const uint64_t i = gbegin + li;
-    const uint64_t p = i & ~(P - 1);
-    uint64_t v = sizeof (SYM) == 1 ? (uint64_t)'a' + splitmix64 (i + 42) % 26 : splitmix64 (i + 42) % vocab;
-    if (n_kw) {
-      const uint64_t off = p + splitmix64 (p) % (P - 16);
-      const uint32_t k = (uint32_t)(splitmix64 (p + 99) % n_kw);
-      const uint32_t len = kw_off[k + 1] - kw_off[k];
-      if (i >= off && i < off + len)
-        v = kw[kw_off[k] + (i - off)];
-    }
-    text[li] = (SYM)v;
-  }
-}
+#include "dev_emit.h"
+#include "dev_dense.h"
+#include "dev_csr.h"
+#include "dev_sparse.h"
+#include "dev_starts.h"
+#include "dev_gram.h"
+#include "dev_misc.h"
 
 } // namespace
 

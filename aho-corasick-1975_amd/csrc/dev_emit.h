@@ -1,0 +1,292 @@
+/* dev_emit.h -- wave helpers, queue items -> records (put_outputs, walk_continuation, flush_queue, expand_items_kernel).
+ * Device code of libac75_amd.so; included by acm_gpu.hip inside its anonymous namespace (one
+ * translation unit: the kernels share the structs and helpers declared there and in dev_emit.h). */
+
+/* ------------------------------------------------------------------ wave helpers */
+__device__ __forceinline__ uint32_t
+lane_id () {
+  return __builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u));
+}
+
+__device__ __forceinline__ uint32_t
+uniform (uint32_t v) { /* tells the compiler the value is the same in every lane */
+  return __builtin_amdgcn_readfirstlane (v);
+}
+
+__device__ __forceinline__ uint32_t
+wave_incl_scan (uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    uint32_t o = __shfl_up (v, d, WAVE);
+    if ((int)lane_id () >= d)
+      v += o;
+  }
+  return v;
+}
+
+/* outputs of state st longer than `bound`, in acm_get_match index order (longest first:
+ * reference aho_corasick.c:459-466): counted, and written from offset o when WRITE.  `oi` is
+ * oinfo[st], already loaded by the caller. */
+template <bool WRITE>
+__device__ __forceinline__ uint32_t
+put_outputs (const EmitCtx &E, uint4 oi, uint32_t pos, uint32_t bound, uint64_t o) {
+  uint32_t cnt = 0;
+  for (uint32_t left = oi.x; left; left--) {
+    if (oi.z <= bound)
+      break;
+    if (WRITE && o + cnt < E.capacity) {
+      const uint64_t gp = E.pos_base + pos;
+      *reinterpret_cast<uint4 *> (&E.records[o + cnt]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), oi.z, oi.w);
+    }
+    cnt++;
+    if (left > 1)
+      oi = E.oinfo[oi.y];
+  }
+  return cnt;
+}
+
+/* what the walk of a continuation item found (it rarely finds more than one match position) */
+struct ContResult {
+  uint32_t cnt;      /* records in all */
+  uint32_t events;   /* positions with records */
+  uint32_t ev_pos, ev_bound; /* the first of them ... */
+  uint4 ev_oi;               /* ... and the oinfo of the state reached there */
+};
+
+/* Ownership in the continuation-mode dense kernel: a match belongs to the chunk in which it
+ * STARTS.  A lane starts from the root at the first byte of its chunk [cs, ce), walks the chunk
+ * and then runs over into the following bytes until its state is no deeper than the number of
+ * bytes past ce (no match that started before ce can still be open); during that run-over only
+ * outputs longer than the bytes past ce are its own.
+ *
+ * Continuation item: at `pos` the lane stepped into a state s that has no row in LDS and carried
+ * on from hotfail(s), the longest suffix state that has one (depth dh).  From there it still finds
+ * every match that starts within the last dh symbols or later; the ones it can no longer see
+ * started earlier and end after pos.  They are recovered here by walking on from s itself
+ * through the HBM rows: j symbols later every output longer than j + dh -- and, past ce, longer
+ * than the bytes past ce -- is such a match, and once the state is no deeper than that bound
+ * nothing more can be missing.
+ * One dependent load per symbol: the row entry carries the next state, its output flag and its
+ * depth; the text byte of the following step is fetched alongside. */
+__device__ __forceinline__ uint32_t
+item_chunk_end (const EmitCtx &E, uint2 it) {
+  return (it.y & IT_RUN) ? it.x + 1 - ((it.y >> IT_K_SHIFT) & 0xFFFu) : (it.x | (E.chunk - 1)) + 1;
+}
+
+template <bool WRITE>
+__device__ __forceinline__ ContResult
+walk_continuation (const EmitCtx &E, uint2 it, uint64_t o) {
+  ContResult r = { 0, 0, 0, 0, make_uint4 (0, 0, 0, 0) };
+  const uint32_t pos = it.x, st = it.y & IT_STATE;
+  const uint32_t dh = E.cont_dh[st];
+  const uint32_t ce = item_chunk_end (E, it);
+  uint32_t s2 = st;
+  uint32_t byte = pos + 1 < E.n ? E.text[pos + 1] : 0;
+  for (uint32_t j = 1; pos + j < E.n; j++) {
+    const uint32_t p = pos + j;
+    const uint32_t ent = E.wrows[s2 * E.W + min (byte - E.lo, E.span)];
+    byte = p + 1 < E.n ? E.text[p + 1] : 0;
+    s2 = ent & IT_STATE;
+    const uint32_t past = p + 1 > ce ? p + 1 - ce : 0;
+    const uint32_t bound = j + dh > past ? j + dh : past;
+    if ((ent >> 16) <= bound)
+      break;
+    if ((ent & 0x8000u) && p >= E.emit_from) {
+      const uint4 oi = E.oinfo[s2];
+      const uint32_t c = put_outputs<WRITE> (E, oi, p, bound, o + r.cnt);
+      if (c) {
+        if (!r.events) {
+          r.ev_pos = p;
+          r.ev_oi = oi;
+          r.ev_bound = bound;
+        }
+        r.events++;
+        r.cnt += c;
+      }
+    }
+  }
+  return r;
+}
+
+/* number of records of one queue item (walks its continuation, remembering what it found) */
+template <bool CONT>
+__device__ __forceinline__ uint32_t
+item_count (const EmitCtx &E, bool valid, uint2 it, uint32_t &own_cnt, uint4 &own_oi, ContResult &r) {
+  const uint32_t st = CONT ? (it.y & IT_STATE) : it.y;
+  if (valid && st >= E.n_states) { /* cannot happen; never index the tables with it */
+    if (E.error)
+      *E.error = 1;
+    valid = false;
+  }
+  const bool own = valid && (!CONT || (it.y & IT_OUT));
+  own_cnt = 0;
+  own_oi = make_uint4 (0, 0, 0, 0);
+  if (own) {
+    own_oi = E.oinfo[st];
+    if (CONT && (it.y & IT_RUN)) /* run-over: only outputs longer than the bytes past the chunk */
+      own_cnt = put_outputs<false> (E, own_oi, it.x, (it.y >> IT_K_SHIFT) & 0xFFFu, 0);
+    else
+      own_cnt = own_oi.x;
+  }
+  r = ContResult{ 0, 0, 0, 0, make_uint4 (0, 0, 0, 0) };
+  if (CONT && valid && (it.y & IT_CONT))
+    r = walk_continuation<false> (E, it, 0);
+  return own_cnt + r.cnt;
+}
+
+/* writes them from offset o: the state's own outputs first, then the continuation's */
+template <bool CONT>
+__device__ __forceinline__ void
+item_write (const EmitCtx &E, uint2 it, uint32_t own_cnt, uint4 own_oi, const ContResult &r, uint64_t o) {
+  if (own_cnt)
+    (void)put_outputs<true> (E, own_oi, it.x, (CONT && (it.y & IT_RUN)) ? ((it.y >> IT_K_SHIFT) & 0xFFFu) : 0u, o);
+  if (r.events == 1)
+    (void)put_outputs<true> (E, r.ev_oi, r.ev_pos, r.ev_bound, o + own_cnt);
+  else if (r.events > 1)
+    (void)walk_continuation<true> (E, it, o + own_cnt);
+}
+
+/* Expand a wave's queue into records: one global atomic per <= 64 items (wave prefix sum of the
+ * per-item counts), records of one item contiguous.  Must be called by all 64 lanes. */
+template <bool CONT, bool COUNT_ONLY>
+__device__ __noinline__ void
+flush_queue (EmitCtx E, const uint2 *queue, uint32_t n_items) {
+  const uint32_t lane = lane_id ();
+  for (uint32_t base = 0; base < n_items; base += WAVE) {
+    const uint32_t i = base + lane;
+    const bool valid = i < n_items;
+    const uint2 it = valid ? queue[i] : make_uint2 (0, 0);
+    uint32_t own_cnt;
+    uint4 own_oi;
+    ContResult r;
+    const uint32_t cnt = item_count<CONT> (E, valid, it, own_cnt, own_oi, r);
+    const uint32_t incl = wave_incl_scan (cnt);
+    const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
+    unsigned long long gbase = 0;
+    if (lane == 0 && total)
+      gbase = atomicAdd (E.count, (unsigned long long)total);
+    gbase = ((unsigned long long)__shfl ((uint32_t)(gbase >> 32), 0, WAVE) << 32) | __shfl ((uint32_t)gbase, 0, WAVE);
+    if (!COUNT_ONLY && cnt)
+      item_write<CONT> (E, it, own_cnt, own_oi, r, gbase + (incl - cnt));
+  }
+}
+
+/* Where a wave of the dense kernel parks its queue when it fills up: a private region of the
+ * plan's item buffer in HBM (plain coalesced stores, nothing to wait for).  expand_items_kernel
+ * turns the parked items into records afterwards with the whole chip's parallelism; a wave whose
+ * region is full expands in place instead (flush_queue), so nothing is ever dropped. */
+struct Spill {
+  uint2 *region;     /* this wave's region */
+  uint32_t capacity; /* items per region */
+  uint32_t fill;     /* items parked so far (wave-uniform) */
+};
+
+template <bool CONT, bool COUNT_ONLY>
+__device__ __forceinline__ void
+queue_drain (const EmitCtx &E, const uint2 *queue, uint32_t qn, Spill *sp, uint32_t lane) {
+  if (sp && sp->fill + qn <= sp->capacity) {
+    for (uint32_t i = lane; i < qn; i += WAVE)
+      sp->region[sp->fill + i] = queue[i];
+    sp->fill = uniform (sp->fill + qn);
+  } else
+    flush_queue<CONT, COUNT_ONLY> (E, queue, qn);
+}
+
+/* append one item per lane with `hit`; wave-uniform bookkeeping in qn */
+template <bool CONT, bool COUNT_ONLY>
+__device__ __forceinline__ void
+queue_push (const EmitCtx &E, uint2 *queue, uint32_t &qn, bool hit, uint32_t pos, uint32_t word, uint32_t lane,
+            Spill *sp = nullptr) {
+  const uint64_t m = __ballot (hit);
+  if (m) {
+    if (hit)
+      queue[qn + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos, word);
+    qn = uniform (qn + (uint32_t)__popcll (m));
+    if (qn > QCAP - WAVE) {
+      queue_drain<CONT, COUNT_ONLY> (E, queue, qn, sp, lane);
+      qn = 0;
+    }
+  }
+}
+
+/* Expands the items parked by REGIONS consecutive waves of the dense kernel: THREADS threads take
+ * THREADS items per round, a block-wide prefix sum of the per-item record counts gives every item
+ * its slot, and ONE global atomic per round reserves the records (a single counter sustains only
+ * ~90 atomics per microsecond, so they are kept to a few hundred per launch).
+ * The launch leaves its own bookkeeping clean: each block zeroes the fill counters it consumed,
+ * and the block that finishes last hands the total to the caller's counter (when this is the
+ * last segment of a scan) and resets the running total and the ticket. */
+struct ExpandTail {
+  unsigned long long *user_count; /* where the caller wants the total */
+  unsigned int *ticket;
+  int last_segment;
+};
+
+template <bool CONT, bool COUNT_ONLY, int THREADS, int REGIONS>
+__global__ __launch_bounds__ (THREADS) void
+expand_items_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint32_t *fill, ExpandTail tail) {
+  __shared__ uint32_t s_off[REGIONS + 1];
+  __shared__ uint32_t s_wave[THREADS / WAVE];
+  __shared__ unsigned long long s_base;
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  if (tid < REGIONS) { /* fill counters of this block's regions: read and zero them in parallel */
+    s_off[tid + 1] = fill[blockIdx.x * REGIONS + tid];
+    fill[blockIdx.x * REGIONS + tid] = 0;
+  }
+  __syncthreads ();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (int r = 0; r < REGIONS; r++) {
+      const uint32_t v = s_off[r + 1];
+      s_off[r] = acc;
+      acc += v;
+    }
+    s_off[REGIONS] = acc;
+  }
+  __syncthreads ();
+  const uint32_t total = s_off[REGIONS];
+  for (uint32_t base = 0; base < total; base += THREADS) {
+    const uint32_t i = base + tid;
+    const bool valid = i < total;
+    uint2 it = make_uint2 (0, 0);
+    if (valid) {
+      uint32_t r = 0;
+#pragma unroll
+      for (int k = 1; k < REGIONS; k++)
+        r += s_off[k] <= i ? 1u : 0u;
+      it = items[(size_t)(blockIdx.x * REGIONS + r) * region_items + (i - s_off[r])];
+    }
+    uint32_t own_cnt;
+    uint4 own_oi;
+    ContResult res;
+    const uint32_t cnt = item_count<CONT> (E, valid, it, own_cnt, own_oi, res);
+    const uint32_t incl = wave_incl_scan (cnt);
+    if (lane == WAVE - 1)
+      s_wave[wid] = incl;
+    __syncthreads ();
+    if (tid == 0) {
+      uint32_t acc = 0;
+      for (int k = 0; k < THREADS / WAVE; k++) {
+        const uint32_t v = s_wave[k];
+        s_wave[k] = acc;
+        acc += v;
+      }
+      s_base = acc ? atomicAdd (E.count, (unsigned long long)acc) : 0ull;
+    }
+    __syncthreads ();
+    if (!COUNT_ONLY && cnt)
+      item_write<CONT> (E, it, own_cnt, own_oi, res, s_base + s_wave[wid] + (incl - cnt));
+    __syncthreads ();
+  }
+  if (tid == 0) {
+    /* this block's adds to the running total have returned (their values were used), so the block
+     * that draws the last ticket sees every add */
+    if (atomicAdd (tail.ticket, 1u) == gridDim.x - 1) {
+      *tail.ticket = 0;
+      if (tail.last_segment) {
+        *tail.user_count = atomicAdd (E.count, 0ull);
+        *E.count = 0;
+      }
+    }
+  }
+}

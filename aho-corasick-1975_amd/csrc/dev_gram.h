@@ -1,0 +1,238 @@
+/* dev_gram.h -- scan_gram_kernel: 4-gram sieve kernel for byte alphabets with big dictionaries.
+ * Device code of libac75_amd.so; included by acm_gpu.hip inside its anonymous namespace (one
+ * translation unit: the kernels share the structs and helpers declared there and in dev_emit.h). */
+
+/* ------------------------------------------------------------------ 4-gram sieve kernel (byte alphabets, big dictionaries)
+ * Dictionaries whose automaton does not fit the LDS scheme of the dense kernel (more than 32,768
+ * states: config 3 has 508,339) make every step of a carried-state walk a dependent gather into
+ * tens of megabytes of rows (99 GB/s).  When every keyword has at least 4 symbols and the
+ * alphabet is small (width W = span + 1 <= 30), the start-parallel idea works for bytes too:
+ *   1. LDS holds one bit per possible 4-gram over the W classes (W^4 bits: 66 KB for a-z): "some
+ *      keyword starts with it".  Every position is tested with one ds_read_b32 on a rolling
+ *      4-gram index (config 3: 19.6% pass);
+ *   2. the survivors are queued per wave as (position, 4-gram index, class of the 5th symbol)
+ *      and checked 64 at a time against an 8-byte record per 4-gram: {terminal bit | 26-bit mask
+ *      of the depth-4 state's children, its state id}; the gather of batch k is in flight
+ *      while the scan fills batch k + 1 (config 3: 3.2% of the positions pass -- all real:
+ *      a keyword of length 4 ends there or a 5-symbol prefix of a keyword does);
+ *   3. those go to walk_starts (shared with the start-parallel kernel) at the depth-4 state.
+ * Text is read as in the start-parallel kernel (1 KiB groups, 16 bytes per lane, four groups in
+ * flight). */
+struct GramK {
+  const uint2 *g4rec;     /* [W^4] {children mask | terminal << 31, state id of the depth-4 node (0: none)} */
+  const uint32_t *g4bits; /* [g4words] one bit per 4-gram, staged in LDS */
+  const uint4 *srec;      /* trie records of the states of depth >= 4, depth-first order (see StartsK::remap) */
+  const uint2 *sedge;
+  const uint32_t *g4gid;  /* [states of depth 4] record index of each depth-4 state */
+  uint32_t d4_begin;      /* breadth-first id of the first depth-4 state */
+  uint32_t g4words;
+  uint32_t W, lo, span, W4; /* class = min (byte - lo, span); W = span + 1 */
+  uint32_t R;             /* groups per tile */
+  uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
+};
+
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__ (SPARSE_THREADS) void
+scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
+                  uint32_t *fill) {
+  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
+  constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
+  constexpr uint32_t GROUP = WAVE * 16;
+  {
+    uint4 *dst = reinterpret_cast<uint4 *> (smem);
+    const uint4 *src = reinterpret_cast<const uint4 *> (K.g4bits);
+    for (uint32_t i = threadIdx.x; i < (K.g4words + 3) / 4; i += blockDim.x)
+      dst[i] = src[i];
+  }
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (2 * QCAP + HITS_STRIDE) * 8);
+  StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4); /* see scan_starts_kernel */
+  EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
+  if (threadIdx.x == 0) {
+    *next_tile = 0;
+    StartsK Kc{};
+    Kc.srec = K.srec;
+    Kc.sedge = K.sedge;
+    Kc.remap = K.g4gid;
+    Kc.remap_base = K.d4_begin;
+    *Ks = Kc;
+    *Es = E;
+  }
+  __syncthreads ();
+
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint32_t wib = uniform (threadIdx.x / WAVE);
+  uint2 *q1 = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
+  uint2 *q2 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * QCAP;
+  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + 2 * WAVES * QCAP + wib * HITS_STRIDE + 2;
+  const uint32_t wave_id = blockIdx.x * WAVES + wib;
+  hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
+  const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
+  /* block b takes the tiles b, b + gridDim.x, ... (match density is rarely even along a text:
+   * contiguous shares left two blocks of config 3 working 1 ms after all others had finished),
+   * handed to its waves through the LDS counter */
+  const uint32_t ntiles = A.range_end - A.range_begin;
+  const uint32_t blk_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const uint32_t last_blk = (A.n - 1) / 16;
+  uint32_t qn1 = 0, qn2 = 0;
+  unsigned long long counted = 0;
+  /* batches of the first queue whose records are in flight: a pipeline of GRAM_DEPTH batches
+   * (the gather of a batch has the time it takes the scan to fill that many more before it is
+   * looked at: one batch ahead left the L2 / MALL latency exposed) */
+  constexpr int GRAM_DEPTH = 3;
+  DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_items = 0, d_b1 = 0, d_cons = 0, d_tiles = 0;)
+  uint2 pend_item[GRAM_DEPTH], pend_rec[GRAM_DEPTH];
+  uint32_t pend_n[GRAM_DEPTH]; /* wave-uniform: items in each pending batch, [0] the oldest */
+#pragma unroll
+  for (int d = 0; d < GRAM_DEPTH; d++) {
+    pend_item[d] = make_uint2 (0, 0);
+    pend_rec[d] = make_uint2 (0, 0);
+    pend_n[d] = 0;
+  }
+
+  auto load_group = [&] (uint32_t g) -> uint4 {
+    const uint32_t blk = g * WAVE + lane;
+    return text16[blk < last_blk ? blk : last_blk];
+  };
+  auto walk_batch = [&] (uint32_t n_items) {
+    DIAG (const unsigned long long d_c0 = __builtin_readcyclecounter ();)
+    const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, true> (Ks, Es, text, q2, qn2, n_items, hits, counted);
+    qn2 = uniform ((uint32_t)(r >> 32));
+    counted = (uint32_t)r;
+    DIAG (d_walk += __builtin_readcyclecounter () - d_c0; d_calls++; d_items += n_items;)
+  };
+  /* second sieve on the oldest pending batch: terminal, or the 5th symbol is an edge of the
+   * depth-4 state; then the pipeline moves up */
+  auto consume_oldest = [&] () {
+    if (pend_n[0]) {
+      const uint32_t c4 = pend_item[0].y >> 20;
+      const bool valid = lane < pend_n[0];
+      /* a keyword of length 4 ends here: reported at once, its record needs nothing but the
+       * state id (the trie records of the 508,339 states are 16 MB of HBM: not worth a visit) */
+      const bool term = valid && (pend_rec[0].x >> 31) && pend_item[0].x + 3 >= E.emit_from;
+      emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, pend_rec[0].y, lane, hits, counted);
+      if (!COUNT_ONLY)
+        counted = uniform ((uint32_t)counted);
+      const bool pass = valid && ((pend_rec[0].x >> c4) & 1u);
+      const uint64_t m = __ballot (pass);
+      if (m) {
+        if (pass)
+          q2[qn2 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pend_item[0].x + 3, pend_rec[0].y | WI_REPORTED);
+        qn2 = uniform (qn2 + (uint32_t)__popcll (m));
+        while (qn2 >= WAVE)
+          walk_batch (WAVE);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d + 1 < GRAM_DEPTH; d++) {
+      pend_item[d] = pend_item[d + 1];
+      pend_rec[d] = pend_rec[d + 1];
+      pend_n[d] = pend_n[d + 1];
+    }
+    pend_n[GRAM_DEPTH - 1] = 0;
+  };
+  /* takes the newest n items of the first queue and sends for their records (the last pipeline
+   * slot is free: consume_oldest ran just before) */
+  auto issue_batch = [&] (uint32_t n_items) {
+    qn1 -= n_items;
+    pend_item[GRAM_DEPTH - 1] = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
+#ifdef GRAM_EXP_NOGATHER
+    pend_rec[GRAM_DEPTH - 1] = make_uint2 (pend_item[GRAM_DEPTH - 1].y >> 3, 1);
+#else
+    pend_rec[GRAM_DEPTH - 1] = K.g4rec[pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu];
+#endif
+    pend_n[GRAM_DEPTH - 1] = n_items;
+  };
+
+  /* one group: cur = this lane's 16 bytes, next_x = the first 4 bytes of every lane of the next group */
+  auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t g) {
+    uint32_t after = __shfl_down (cur.x, 1, WAVE);
+    const uint32_t after_group = uniform (next_x);
+    if (lane == WAVE - 1)
+      after = after_group;
+    const uint32_t pos0 = g * GROUP + lane * 16;
+    const uint32_t w[5] = { cur.x, cur.y, cur.z, cur.w, after };
+    uint32_t c[20];
+#pragma unroll
+    for (int j = 0; j < 20; j++) {
+      const uint32_t b = (w[j / 4] >> (8 * (j % 4))) & 0xFFu;
+      c[j] = min (b - K.lo, K.span);
+    }
+    /* symbols past the end of the segment count as outside the alphabet (only the last groups) */
+    if (pos0 + 20 > A.n) {
+#pragma unroll
+      for (int j = 0; j < 20; j++)
+        if (pos0 + j >= A.n)
+          c[j] = K.span;
+    }
+    uint32_t idx = ((c[0] * K.W + c[1]) * K.W + c[2]) * K.W + c[3];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t word = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
+      const bool push = (word >> (idx & 31u)) & 1u;
+      const uint64_t m = __ballot (push);
+      if (m) {
+        if (push)
+          q1[qn1 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos0 + j, idx | (c[j + 4] << 20));
+        qn1 = uniform (qn1 + (uint32_t)__popcll (m));
+        if (qn1 >= WAVE) {
+          DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)
+          consume_oldest ();
+          issue_batch (WAVE);
+          DIAG (d_cons += __builtin_readcyclecounter () - d_c1; d_b1++;)
+        }
+      }
+      idx = idx * K.W + c[j + 4] - c[j] * K.W4;
+    }
+  };
+
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0)
+      t = atomicAdd (next_tile, 1u);
+    t = uniform (t);
+    if (t >= blk_tiles)
+      break;
+    DIAG (d_tiles++;)
+    const uint32_t g0 = (A.range_begin + t * gridDim.x + blockIdx.x) * K.R;
+    uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
+    for (uint32_t k = 0; k < K.R; k++) {
+      const uint4 n3 = load_group (g0 + k + 4);
+      walk_group (c0, c1.x, g0 + k);
+      c0 = c1;
+      c1 = c2;
+      c2 = c3;
+      c3 = n3;
+    }
+  }
+  if (qn1) {
+    consume_oldest ();
+    issue_batch (qn1);
+  }
+#pragma unroll
+  for (int d = 0; d < GRAM_DEPTH; d++)
+    consume_oldest ();
+  while (qn2)
+    walk_batch (qn2 < WAVE ? qn2 : WAVE);
+  if (COUNT_ONLY) {
+    const uint32_t incl = wave_incl_scan ((uint32_t)counted);
+    const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
+    if (lane == 0 && total)
+      atomicAdd (E.count, (unsigned long long)total);
+  } else {
+    if (counted)
+      flush_hits (E, hits, (uint32_t)counted, lane);
+    if (lane == 0 && fill)
+      fill[wave_id] = hits[-1].y;
+  }
+  DIAG (if (lane == 0 && wave_id < 8192) {
+    unsigned long long *o = g_acm_diag[wave_id];
+    o[0] = __builtin_readcyclecounter () - d_t0;
+    o[1] = d_walk;
+    o[2] = d_calls;
+    o[3] = d_items;
+    o[4] = d_b1;
+    o[5] = d_cons;
+    o[6] = wall_clock64 ();
+    o[7] = d_tiles;
+  })
+}

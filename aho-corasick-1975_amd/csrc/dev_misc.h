@@ -1,0 +1,91 @@
+/* dev_misc.h -- classmap, patch, sort-key and synthetic-text kernels.
+ * Device code of libac75_amd.so; included by acm_gpu.hip inside its anonymous namespace (one
+ * translation unit: the kernels share the structs and helpers declared there and in dev_emit.h). */
+
+/* ------------------------------------------------------------------ comparator classes
+ * Plans of machines flattened over comparator classes (acm_flatten_classes) map the text to
+ * class ids first: one table of 65,536 16-bit entries in LDS serves both symbol sizes -- 2-byte
+ * symbols index it directly, bytes go through it two at a time ((class(hi) << 8) | class(lo)), so
+ * either way it is one ds_read_u16 per two bytes of text. */
+__global__ __launch_bounds__ (1024) void
+classmap_kernel (const uint4 *__restrict__ in, uint4 *__restrict__ out, uint64_t n_blocks16, const uint16_t *__restrict__ lut) {
+  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
+  {
+    uint4 *dst = reinterpret_cast<uint4 *> (smem);
+    const uint4 *src = reinterpret_cast<const uint4 *> (lut);
+    for (uint32_t i = threadIdx.x; i < 65536 * 2 / 16; i += blockDim.x)
+      dst[i] = src[i];
+  }
+  __syncthreads ();
+  const uint16_t *l = reinterpret_cast<const uint16_t *> (smem);
+  auto map2 = [&] (uint32_t w) -> uint32_t { return (uint32_t)l[w & 0xFFFFu] | ((uint32_t)l[w >> 16] << 16); };
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks16; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 v = in[i];
+    out[i] = make_uint4 (map2 (v.x), map2 (v.y), map2 (v.z), map2 (v.w));
+  }
+}
+
+/* element-wise form for the last bytes of a buffer and for buffers that are not 16-byte aligned */
+template <typename SYM>
+__global__ void
+classmap_tail_kernel (const SYM *__restrict__ in, SYM *__restrict__ out, uint64_t begin, uint64_t n, const uint16_t *__restrict__ lut) {
+  for (uint64_t i = begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    out[i] = (SYM)lut[in[i]]; /* a byte v indexes entry (0 << 8) | v: class(v) in its low byte */
+}
+
+/* ------------------------------------------------------------------ incremental updates
+ * word patches for the tables of the start-parallel kernel: {table, index, value, -} */
+struct PatchTables {
+  uint32_t *t[5];
+};
+__global__ void
+patch_kernel (PatchTables T, const uint4 *__restrict__ patches, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint4 q = patches[i];
+    T.t[q.x][q.y] = q.z;
+  }
+}
+
+/* ------------------------------------------------------------------ sort keys */
+__global__ void
+make_keys_kernel (const ACMRecord *rec, uint64_t n, uint32_t len_bits, uint64_t *keys) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint64_t lmask = (1ull << len_bits) - 1;
+    keys[i] = (rec[i].end_pos << len_bits) | (lmask - (rec[i].length & lmask));
+  }
+}
+
+struct Rec16 {
+  uint64_t a, b;
+};
+
+/* ------------------------------------------------------------------ synthetic text */
+__device__ __forceinline__ uint64_t
+splitmix64 (uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+template <typename SYM>
+__global__ void
+synth_text_kernel (SYM *text, uint64_t n, uint64_t gbegin, uint32_t vocab, const SYM *kw, const uint32_t *kw_off, uint32_t n_kw) {
+  constexpr uint64_t P = 4096;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; li < n; li += stride) {
+    const uint64_t i = gbegin + li;
+    const uint64_t p = i & ~(P - 1);
+    uint64_t v = sizeof (SYM) == 1 ? (uint64_t)'a' + splitmix64 (i + 42) % 26 : splitmix64 (i + 42) % vocab;
+    if (n_kw) {
+      const uint64_t off = p + splitmix64 (p) % (P - 16);
+      const uint32_t k = (uint32_t)(splitmix64 (p + 99) % n_kw);
+      const uint32_t len = kw_off[k + 1] - kw_off[k];
+      if (i >= off && i < off + len)
+        v = kw[kw_off[k] + (i - off)];
+    }
+    text[li] = (SYM)v;
+  }
+}

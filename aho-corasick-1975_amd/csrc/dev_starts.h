@@ -1,0 +1,427 @@
+/* dev_starts.h -- scan_starts_kernel: start-parallel kernel for 2- and 4-byte symbols; walk_starts, hit parking, expand_hits_kernel.
+ * Device code of libac75_amd.so; included by acm_gpu.hip inside its anonymous namespace (one
+ * translation unit: the kernels share the structs and helpers declared there and in dev_emit.h). */
+
+/* ------------------------------------------------------------------ start-parallel kernel (2- and 4-byte symbols)
+ * The same match set, computed without a state carried from symbol to symbol: a keyword occurs
+ * at [i, i + L) iff the goto function alone (the trie, no failure transitions) leads from the root
+ * through text[i .. i + L) to its terminal state.  With a large alphabet nearly every start dies
+ * at once, so instead of one dependent table lookup per symbol (the sparse walk above waits
+ * ~2.7 us of memory latency per step) every position is tested independently, in three sieves:
+ *   1. one LDS lookup per symbol in the root table: child state | ALWAYS << 31 | SECOND << 30
+ *      (SECOND: the symbol is the second symbol of some keyword).  A start survives if its
+ *      symbol has a child and the next symbol has SECOND (config 5: 7% of the positions);
+ *   2. the two smallest edge symbols of the child (8 bytes, a 69 KB table on config 5) against
+ *      the next symbol -- the load is issued at once and looked at one group (1 KiB of text)
+ *      later, so nobody waits for it.  Children that are keywords themselves or have more than
+ *      two edges carry ALWAYS and pass both sieves unseen;
+ *   3. what is left (config 5: 3 starts per 10,000 symbols) is queued per wave and walked down
+ *      the trie 64 at a time (walk_starts); terminal states give records (end position, depth,
+ *      keyword id).
+ * The text is read the coalesced way: a wave takes 1 KiB groups, lane l the 16 bytes at 16 l,
+ * four groups walked while the next four are in flight.  Every record belongs to the start
+ * position that finds it: nothing is warmed up, nothing is found twice.  Worst case (every start
+ * walks lmax symbols) is lmax dependent loads per symbol; ACM_GPU_SPARSE=walk selects the sparse
+ * automaton walk instead. */
+struct StartsK {
+  const uint4 *srec;   /* 2 x uint4 per state: {-, n_edges, edge_begin, terminal} {sym0, next0, sym1, next1} */
+  const uint2 *sedge;  /* per goto edge, rows in ascending symbol order: {symbol, next} */
+  const uint2 *pairs;  /* states 0 .. root fan-out: the symbols of the first two edges (repeated / 0 when fewer) */
+  const uint32_t *lut; /* by symbol value: child | SECOND << 30 | ALWAYS << 31 */
+  uint32_t lut_size;
+  uint32_t R;          /* groups per tile, a multiple of 4 */
+  uint32_t queue_off;  /* LDS: [lut if staged][16 queues of 128][16 hit buffers of 64][tile counter] */
+  /* 4-gram kernel only: its records are laid out depth-first below depth 4 (a keyword's tail in
+   * consecutive records); an item names a depth-4 state by its breadth-first id, remap[id -
+   * remap_base] is its record, and word 0 of a record is the state's breadth-first id */
+  const uint32_t *remap;
+  uint32_t remap_base;
+};
+constexpr uint32_t ST_ALWAYS = 0x80000000u, ST_SECOND = 0x40000000u, ST_STATE = 0x3FFFFFFFu;
+
+/* Matches found by a wave collect in its LDS hit buffer as (end position, terminal state) and
+ * leave up to 64 at a time for the wave's private region of the plan's item buffer in HBM (plain
+ * coalesced stores); expand_hits_kernel turns the regions into records afterwards with one atomic
+ * per block.  (One atomic on the record counter per find was 0.7 ms of serialised atomics on
+ * config 5, one per 64 finds still 6 ms on config 3's 27 M matches: a single address sustains
+ * ~90 atomics per microsecond.)  A full region falls back to records straight from here.
+ * LDS per wave: [region pointer][capacity, fill][64 hits]. */
+constexpr uint32_t HITS_STRIDE = WAVE + 2; /* in 8-byte units */
+
+__device__ __forceinline__ void
+hits_init (uint2 *hits, uint2 *region, uint32_t capacity, uint32_t lane) {
+  if (lane == 0) {
+    const uint64_t a = reinterpret_cast<uint64_t> (region);
+    hits[-2] = make_uint2 ((uint32_t)a, (uint32_t)(a >> 32));
+    hits[-1] = make_uint2 (region ? capacity : 0u, 0u);
+  }
+}
+
+__device__ __forceinline__ void
+flush_hits (const EmitCtx &E, uint2 *hits, uint32_t n, uint32_t lane) {
+  const uint2 rp = hits[-2], cf = hits[-1];
+  if (cf.y + n <= cf.x) {
+    uint2 *region = reinterpret_cast<uint2 *> (((uint64_t)rp.y << 32) | rp.x);
+    if (lane < n)
+      region[cf.y + lane] = hits[lane];
+    if (lane == 0)
+      hits[-1] = make_uint2 (cf.x, cf.y + n);
+    return;
+  }
+  unsigned long long base = 0;
+  if (lane == 0)
+    base = atomicAdd (E.count, (unsigned long long)n);
+  base = ((unsigned long long)__shfl ((uint32_t)(base >> 32), 0, WAVE) << 32) | __shfl ((uint32_t)base, 0, WAVE);
+  if (lane < n && base + lane < E.capacity) {
+    const uint2 h = hits[lane];
+    const uint4 oi = E.oinfo[h.y]; /* terminal state: its first output is its own keyword */
+    const uint64_t gp = E.pos_base + h.x;
+    *reinterpret_cast<uint4 *> (&E.records[base + lane]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), oi.z, oi.w);
+  }
+}
+
+/* one record per parked hit; a block takes REGIONS consecutive regions and reserves their
+ * records with one atomic; it zeroes the fill counters it consumed */
+template <int THREADS, int REGIONS>
+__global__ __launch_bounds__ (THREADS) void
+expand_hits_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint32_t *fill, uint32_t n_regions) {
+  __shared__ uint32_t s_off[REGIONS + 1];
+  __shared__ unsigned long long s_base;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t r0 = blockIdx.x * REGIONS;
+  if (tid < REGIONS) {
+    const uint32_t r = r0 + tid;
+    s_off[tid + 1] = r < n_regions ? fill[r] : 0;
+    if (r < n_regions)
+      fill[r] = 0;
+  }
+  __syncthreads ();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (int r = 0; r < REGIONS; r++) {
+      const uint32_t v = s_off[r + 1];
+      s_off[r] = acc;
+      acc += v;
+    }
+    s_off[REGIONS] = acc;
+    s_base = acc ? atomicAdd (E.count, (unsigned long long)acc) : 0ull;
+  }
+  __syncthreads ();
+  const uint32_t total = s_off[REGIONS];
+  const unsigned long long base = s_base;
+  for (uint32_t i = tid; i < total; i += THREADS) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 1; k < REGIONS; k++)
+      r += s_off[k] <= i ? 1u : 0u;
+    const uint2 h = items[(size_t)(r0 + r) * region_items + (i - s_off[r])];
+    if (base + i < E.capacity) {
+      const uint4 oi = E.oinfo[h.y];
+      const uint64_t gp = E.pos_base + h.x;
+      *reinterpret_cast<uint4 *> (&E.records[base + i]) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), oi.z, oi.w);
+    }
+  }
+}
+
+/* tally: this lane's finds (count-only mode; summed over the wave at the end of the kernel) or
+ * the fill of the hit buffer (record mode, wave-uniform) */
+template <bool COUNT_ONLY>
+__device__ __forceinline__ void
+emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t lane, uint2 *hits, unsigned long long &tally) {
+  if (COUNT_ONLY) {
+    tally += hit ? 1u : 0u;
+    return;
+  }
+  const uint64_t m = __ballot (hit);
+  if (m) {
+    const uint32_t total = (uint32_t)__popcll (m);
+    uint32_t hn = (uint32_t)tally;
+    if (hn + total > WAVE) {
+      flush_hits (E, hits, hn, lane);
+      hn = 0;
+    }
+    if (hit)
+      hits[hn + (uint32_t)__popcll (m & ((1ull << lane) - 1))] = make_uint2 (p, st);
+    tally = hn + total;
+  }
+}
+
+/* third sieve: the newest n_items (<= 64) of a wave's queue, item = (position p of the last
+ * symbol read, state reached | flags).  ONE level per call: report the state if it is terminal,
+ * look its goto edge on text[p + 1] up, and put the starts that go on back into the queue -- the
+ * few long walks (a planted keyword of 12 symbols) then travel in full batches with everybody
+ * else's instead of holding 63 idle lanes for 8 rounds of memory latency each.
+ * Returns (new queue fill << 32) | tally.
+ * (The structs come by pointer to copies the caller makes on the spot: taking the address of the
+ * kernel's own K and E would move them from scalar registers to scratch memory for the whole
+ * kernel -- measured 2x on the main loop.) */
+constexpr uint32_t WALK_CTX_K = 128, WALK_CTX_BYTES = 16 + 128 + 256; /* LDS after the tile counter: StartsK, EmitCtx */
+static_assert (sizeof (StartsK) <= WALK_CTX_K && sizeof (EmitCtx) <= 256, "walk context does not fit its LDS slot");
+constexpr uint32_t WI_REPORTED = 0x80000000u; /* what ends in this state has been reported by the caller */
+constexpr uint32_t WI_RECORD = 0x40000000u;   /* 4-gram kernel: the index is a record index already (StartsK::remap) */
+template <typename SYM, bool COUNT_ONLY, bool GRAM = false>
+__device__ __noinline__ unsigned long long
+walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue, uint32_t qn, uint32_t n_items, uint2 *hits,
+             unsigned long long counted) {
+  const StartsK &K = *Kp;
+  const EmitCtx &E = *Ep;
+  const uint32_t lane = lane_id ();
+  const uint32_t base = qn - n_items;
+  const bool alive = lane < n_items;
+  const uint2 it = alive ? queue[base + lane] : make_uint2 (0, 0);
+  const uint32_t p = it.x;
+  uint32_t st = it.y & ST_STATE;
+  if (GRAM && !(it.y & WI_RECORD))
+    st = alive ? K.remap[st - K.remap_base] : 0u;
+  const uint4 ra = K.srec[2 * st], rb = K.srec[2 * st + 1];
+  const bool more = alive && p + 1 < E.n;
+  const uint32_t c1 = more ? (uint32_t)text[p + 1] : 0u;
+  emit_terminals<COUNT_ONLY> (E, alive && !(it.y & WI_REPORTED) && ra.w != 0 && p >= E.emit_from, p, GRAM ? ra.x : st, lane, hits,
+                              counted);
+  uint32_t nx = NONE;
+  if (more) {
+    const uint32_t ne = ra.y;
+    if (ne >= 1 && rb.x == c1)
+      nx = rb.y;
+    else if (ne >= 2 && rb.z == c1)
+      nx = rb.w;
+    else if (ne > 2) {
+      uint32_t lo = ra.z, hi = ra.z + ne;
+      while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (K.sedge[mid].x < c1)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      if (lo < ra.z + ne) {
+        const uint2 e = K.sedge[lo];
+        if (e.x == c1)
+          nx = e.y;
+      }
+    }
+  }
+  const bool go = nx != NONE;
+  const uint64_t m = __ballot (go);
+  if (go)
+    queue[base + (uint32_t)__popcll (m & ((1ull << lane) - 1))] = make_uint2 (p + 1, nx | (GRAM ? WI_RECORD : 0u));
+  const uint32_t fill = base + (uint32_t)__popcll (m);
+  if (COUNT_ONLY)
+    return ((unsigned long long)fill << 32) | (uint32_t)counted;
+  /* record mode: the tally is the fill of the hit buffer, one value for the wave */
+  return ((unsigned long long)fill << 32) | uniform ((uint32_t)counted);
+}
+
+template <bool LUT_LDS>
+__device__ __forceinline__ uint32_t
+starts_root (const StartsK &K, uint32_t c) {
+  if (c < K.lut_size) {
+    if (LUT_LDS)
+      return *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (c * 4u);
+    return K.lut[c];
+  }
+  /* beyond the table: bisect the root row; no sieve can be applied, let everything pass */
+  const uint4 a = K.srec[0];
+  uint32_t lo = a.z, hi = a.z + a.y;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (K.sedge[mid].x < c)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo < a.z + a.y) {
+    const uint2 e = K.sedge[lo];
+    if (e.x == c)
+      return e.y | ST_SECOND | ST_ALWAYS;
+  }
+  return ST_SECOND;
+}
+
+/* a start between the first and the second sieve */
+struct PendingStart {
+  uint2 pair;     /* the child's first two edge symbols (load in flight) */
+  uint32_t ntok;  /* the symbol after the start */
+  uint32_t child; /* root-table entry of the start's symbol; 0 = none pending */
+  uint32_t pos;
+};
+
+template <typename SYM, bool LUT_LDS, bool COUNT_ONLY>
+__global__ __launch_bounds__ (SPARSE_THREADS) void
+scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text8, uint2 *items, uint32_t region_items,
+                    uint32_t *fill) {
+  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
+  constexpr uint32_t PER = 16 / sizeof (SYM);  /* symbols per lane per group */
+  constexpr uint32_t PERW = 4 / sizeof (SYM);  /* symbols per 32-bit word */
+  constexpr uint32_t GROUP = WAVE * PER;
+  constexpr uint32_t SYM_MASK = sizeof (SYM) == 4 ? 0xFFFFFFFFu : (1u << (8 * (sizeof (SYM) & 3))) - 1u;
+  if (LUT_LDS) {
+    uint4 *dst = reinterpret_cast<uint4 *> (smem);
+    const uint4 *src = reinterpret_cast<const uint4 *> (K.lut);
+    for (uint32_t i = threadIdx.x; i < (K.lut_size + 3) / 4; i += blockDim.x)
+      dst[i] = src[i];
+  }
+  constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (QCAP + HITS_STRIDE) * 8);
+  /* what walk_starts needs of K and E, once per block in LDS: handing it the kernel's own
+   * structs by address would move them from scalar registers to scratch for the whole kernel,
+   * and a copy per call is 13 KB of scratch traffic per wave and call */
+  StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4);
+  EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
+  if (threadIdx.x == 0) {
+    *next_tile = 0;
+    *Ks = K;
+    *Es = E;
+  }
+  __syncthreads ();
+
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint32_t wib = uniform (threadIdx.x / WAVE);
+  uint2 *queue = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
+  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * HITS_STRIDE + 2;
+  const uint32_t wave_id = blockIdx.x * WAVES + wib;
+  hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
+  const SYM *text = reinterpret_cast<const SYM *> (text8);
+  const uint4 *text16 = reinterpret_cast<const uint4 *> (text8);
+  /* block b takes the tiles b, b + gridDim.x, ... (match density is rarely even along a text:
+   * contiguous shares left two blocks of config 3 working 1 ms after all others had finished),
+   * handed to its waves through the LDS counter */
+  const uint32_t ntiles = A.range_end - A.range_begin;
+  const uint32_t blk_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const uint32_t last_blk = (uint32_t)(((uint64_t)A.n * sizeof (SYM) - 1) / 16);
+  uint32_t qn = 0;
+  unsigned long long counted = 0;
+  DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_cands = 0, d_deep = 0, d_tiles = 0;)
+  PendingStart pend[4][PERW];
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+#pragma unroll
+    for (uint32_t i = 0; i < PERW; i++)
+      pend[w][i].child = 0;
+
+  auto load_group = [&] (uint32_t g) -> uint4 {
+    const uint32_t blk = g * WAVE + lane;
+#ifdef ST_EXP_NT
+    typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+    const v4u v = __builtin_nontemporal_load (reinterpret_cast<const v4u *> (&text16[blk < last_blk ? blk : last_blk]));
+    return make_uint4 (v.x, v.y, v.z, v.w);
+#else
+    return text16[blk < last_blk ? blk : last_blk];
+#endif
+  };
+  /* second sieve on a start whose pair has arrived; survivors go to the wave's queue */
+  auto resolve = [&] (PendingStart &P) {
+    const bool deep = P.child != 0 && ((P.child & ST_ALWAYS) || P.pair.x == P.ntok || P.pair.y == P.ntok);
+    const uint64_t m = __ballot (deep);
+    if (m) {
+      if (deep)
+        queue[qn + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (P.pos, P.child & ST_STATE);
+      qn = uniform (qn + (uint32_t)__popcll (m));
+      while (qn >= WAVE) {
+        DIAG (const unsigned long long d_c0 = __builtin_readcyclecounter ();)
+        {
+          const unsigned long long r = walk_starts<SYM, COUNT_ONLY> (Ks, Es, text, queue, qn, WAVE, hits, counted);
+          qn = uniform ((uint32_t)(r >> 32));
+          counted = (uint32_t)r;
+        }
+        DIAG (d_walk += __builtin_readcyclecounter () - d_c0; d_calls++;)
+      }
+    }
+    DIAG (d_cands += __popcll (__ballot (P.child != 0)); d_deep += __popcll (m);)
+    P.child = 0;
+  };
+  /* first sieve on the start at position p: e0 = entry of its symbol, e1 = entry of the next
+   * symbol (0 when there is none), ntok = the next symbol */
+  auto sieve = [&] (PendingStart &P, uint32_t e0, uint32_t e1, uint32_t ntok, uint32_t p) {
+    resolve (P); /* the start that used this slot one group ago */
+    /* (straight-line: every lane loads, the ones without a start pairs[0]; a load under a branch
+     * would make the compiler wait for everything in flight, prefetched text included) */
+    const bool cand = (e0 & ST_STATE) != 0 && ((e0 & ST_ALWAYS) || (e1 & ST_SECOND));
+    P.child = cand ? e0 : 0u;
+    P.pair = K.pairs[P.child & ST_STATE];
+    P.ntok = ntok;
+    P.pos = p;
+  };
+  /* one group: `cur` = this lane's 16 bytes, next_x = word 0 of every lane of the following group */
+  auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t g) {
+    const uint32_t pos0 = g * GROUP + lane * PER; /* position of this lane's first symbol */
+    /* word 0 of the next lane (of the next group for lane 63): holds the successor of this lane's last symbol */
+    uint32_t after = __shfl_down (cur.x, 1, WAVE);
+    const uint32_t after_group = uniform (next_x);
+    if (lane == WAVE - 1)
+      after = after_group;
+    const uint32_t words[5] = { cur.x, cur.y, cur.z, cur.w, after };
+    uint32_t e_first = pos0 < A.n ? starts_root<LUT_LDS> (K, cur.x & SYM_MASK) : 0u;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint32_t p = pos0 + w * PERW;
+      const uint32_t ntok_word = words[w + 1] & SYM_MASK;
+      const uint32_t e_next = p + PERW < A.n ? starts_root<LUT_LDS> (K, ntok_word) : 0u;
+      if (PERW == 2) {
+        const uint32_t mid = words[w] >> 16;
+        const uint32_t e_mid = p + 1 < A.n ? starts_root<LUT_LDS> (K, mid) : 0u;
+        sieve (pend[w][0], e_first, e_mid, mid, p);
+        sieve (pend[w][PERW - 1], e_mid, e_next, ntok_word, p + 1);
+      } else
+        sieve (pend[w][0], e_first, e_next, ntok_word, p);
+      e_first = e_next;
+    }
+  };
+
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0)
+      t = atomicAdd (next_tile, 1u);
+    t = uniform (t);
+    if (t >= blk_tiles)
+      break;
+    DIAG (d_tiles++;)
+    const uint32_t g0 = (A.range_begin + t * gridDim.x + blockIdx.x) * K.R;
+    uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
+    for (uint32_t k = 0; k < K.R; k += 4) {
+      const uint32_t g = g0 + k;
+      const uint4 n0 = load_group (g + 4), n1 = load_group (g + 5), n2 = load_group (g + 6), n3 = load_group (g + 7);
+      walk_group (c0, c1.x, g);
+      walk_group (c1, c2.x, g + 1);
+      walk_group (c2, c3.x, g + 2);
+      walk_group (c3, n0.x, g + 3);
+      c0 = n0;
+      c1 = n1;
+      c2 = n2;
+      c3 = n3;
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+#pragma unroll
+    for (uint32_t i = 0; i < PERW; i++)
+      resolve (pend[w][i]);
+  while (qn) {
+    const unsigned long long r = walk_starts<SYM, COUNT_ONLY> (Ks, Es, text, queue, qn, qn < WAVE ? qn : WAVE, hits, counted);
+    qn = uniform ((uint32_t)(r >> 32));
+    counted = (uint32_t)r;
+  }
+  if (COUNT_ONLY) {
+    const uint32_t incl = wave_incl_scan ((uint32_t)counted); /* a lane finds far fewer than 2^32 / 64 */
+    const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
+    if (lane == 0 && total)
+      atomicAdd (E.count, (unsigned long long)total);
+  } else {
+    if (counted)
+      flush_hits (E, hits, (uint32_t)counted, lane);
+    if (lane == 0 && fill)
+      fill[wave_id] = hits[-1].y;
+  }
+  DIAG (if (lane == 0) {
+    const uint32_t wave = blockIdx.x * (SPARSE_THREADS / WAVE) + wib;
+    if (wave < 8192) {
+      unsigned long long *o = g_acm_diag[wave];
+      o[0] = __builtin_readcyclecounter () - d_t0;
+      o[1] = d_walk;
+      o[2] = d_calls;
+      o[3] = d_cands;
+      o[4] = d_deep;
+      o[5] = d_tiles;
+    }
+  })
+}
