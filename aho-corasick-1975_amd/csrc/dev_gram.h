@@ -12,10 +12,11 @@
  *      4-gram index (config 3: 19.6% pass);
  *   2. the survivors are queued per wave as (position, 4-gram index, class of the 5th symbol)
  *      and checked 64 at a time against an 8-byte record per 4-gram: {terminal bit | 26-bit mask
- *      of the depth-4 state's children, its state id}; the gather of batch k is in flight
- *      while the scan fills batch k + 1 (config 3: 3.2% of the positions pass -- all real:
- *      a keyword of length 4 ends there or a 5-symbol prefix of a keyword does);
- *   3. those go to walk_starts (shared with the start-parallel kernel) at the depth-4 state.
+ *      of the depth-4 state's children, its state id}; three batches are in flight behind the
+ *      scan (config 3: 3.2% of the positions pass -- all real: a keyword of length 4 ends there,
+ *      reported on the spot, or a 5-symbol prefix of a keyword does);
+ *   3. the latter (0.75%) go to walk_starts (shared with the start-parallel kernel) at the
+ *      depth-4 state; the trie records below depth 4 are laid out depth-first.
  * Text is read as in the start-parallel kernel (1 KiB groups, 16 bytes per lane, four groups in
  * flight). */
 struct GramK {
@@ -165,23 +166,34 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           c[j] = K.span;
     }
     uint32_t idx = ((c[0] * K.W + c[1]) * K.W + c[2]) * K.W + c[3];
+    /* eight positions at a time: all their table words are asked for before any is looked at
+     * (slot by slot, every ds_read waited behind the queue's ds_write of the slot before it,
+     * which the compiler must assume to alias: 16 LDS round trips in a row per group) */
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint32_t word = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
-      const bool push = (word >> (idx & 31u)) & 1u;
-      const uint64_t m = __ballot (push);
-      if (m) {
-        if (push)
-          q1[qn1 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos0 + j, idx | (c[j + 4] << 20));
-        qn1 = uniform (qn1 + (uint32_t)__popcll (m));
-        if (qn1 >= WAVE) {
-          DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)
-          consume_oldest ();
-          issue_batch (WAVE);
-          DIAG (d_cons += __builtin_readcyclecounter () - d_c1; d_b1++;)
+    for (int h = 0; h < 2; h++) {
+      uint32_t ix[8], word[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        ix[j] = idx;
+        word[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
+        idx = idx * K.W + c[8 * h + j + 4] - c[8 * h + j] * K.W4;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const bool push = (word[j] >> (ix[j] & 31u)) & 1u;
+        const uint64_t m = __ballot (push);
+        if (m) {
+          if (push)
+            q1[qn1 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos0 + 8 * h + j, ix[j] | (c[8 * h + j + 4] << 20));
+          qn1 = uniform (qn1 + (uint32_t)__popcll (m));
+          if (qn1 >= WAVE) {
+            DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)
+            consume_oldest ();
+            issue_batch (WAVE);
+            DIAG (d_cons += __builtin_readcyclecounter () - d_c1; d_b1++;)
+          }
         }
       }
-      idx = idx * K.W + c[j + 4] - c[j] * K.W4;
     }
   };
 
