@@ -408,14 +408,12 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const size_t o_tpairs = blob_reserve (cur, starts ? (size_t)n * 8 : 0); /* by state id; filled for the root's children */
   /* 4-gram sieve kernel: byte alphabets of width <= 30 whose automaton is too big for the LDS
    * scheme, every keyword at least 4 symbols long */
-  bool gram = dense && entry_bytes == 4 && fi.width <= 30 && fi.width == fi.alpha_span + 1 && fi.lmax >= 4 && n < 0x40000000u;
-  if (gram) {
-    for (uint32_t k = 0; k < fi.n_keywords && gram; k++)
-      gram = fv.depth[fv.kw_state[k]] >= 4;
-    const char *e = getenv ("ACM_GPU_GRAM");
-    if (e && atoi (e) == 0)
-      gram = false;
-  }
+  const char *gram_env = getenv ("ACM_GPU_GRAM"); /* 0: never; 2: also for dictionaries the LDS scheme takes (experiments) */
+  const int gram_mode = gram_env ? atoi (gram_env) : 1;
+  bool gram = dense && (entry_bytes == 4 || gram_mode == 2) && gram_mode != 0 && fi.width <= 30 && fi.width == fi.alpha_span + 1 &&
+              fi.lmax >= 4 && n < 0x40000000u && fi.lmax + 1 >= 5;
+  for (uint32_t k = 0; k < fi.n_keywords && gram; k++)
+    gram = fv.depth[fv.kw_state[k]] >= 4;
   const uint32_t gW = fi.width;
   const uint32_t gW4 = gram ? gW * gW * gW * gW : 0;
   const uint32_t g4words = (gW4 + 31) / 32;

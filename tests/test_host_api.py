@@ -22,6 +22,21 @@ def test_library_exports_every_declared_symbol():
     assert C.c_int.in_dll(L, "ACM_INCREMENTAL_STRING_MATCHING").value == 1
 
 
+def test_export_list_covers_the_headers():
+    """Every function the public headers declare is in the binding's EXPORTS list (which the two
+    tests around this one check against the library), so the list cannot fall behind the headers."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = set()
+    for h in ("acm.h", "acm_gpu.h"):
+        text = open(os.path.join(root, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)                 # comments mention functions too
+        declared |= set(re.findall(r"\b(acm_[a-z0-9_]+)\s*\(", text))
+        declared |= set(re.findall(r"\b(ACM_[A-Z_]+)\s*;", text))
+    missing = sorted(n for n in declared if n not in acm.binding.EXPORTS)
+    assert not missing, missing
+
+
 def test_headers_declare_what_the_library_exports():
     """include/acm.h + include/acm_gpu.h compile as C11 and every declared function links."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
