@@ -136,11 +136,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   auto issue_batch = [&] (uint32_t n_items) {
     qn1 -= n_items;
     pend_item[GRAM_DEPTH - 1] = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
-#ifdef GRAM_EXP_NOGATHER
-    pend_rec[GRAM_DEPTH - 1] = make_uint2 (pend_item[GRAM_DEPTH - 1].y >> 3, 1);
-#else
     pend_rec[GRAM_DEPTH - 1] = K.g4rec[pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu];
-#endif
     pend_n[GRAM_DEPTH - 1] = n_items;
   };
 

@@ -301,13 +301,7 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
 
   auto load_group = [&] (uint32_t g) -> uint4 {
     const uint32_t blk = g * WAVE + lane;
-#ifdef ST_EXP_NT
-    typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
-    const v4u v = __builtin_nontemporal_load (reinterpret_cast<const v4u *> (&text16[blk < last_blk ? blk : last_blk]));
-    return make_uint4 (v.x, v.y, v.z, v.w);
-#else
     return text16[blk < last_blk ? blk : last_blk];
-#endif
   };
   /* second sieve on a start whose pair has arrived; survivors go to the wave's queue */
   auto resolve = [&] (PendingStart &P) {
