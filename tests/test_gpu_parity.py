@@ -622,6 +622,10 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
     got = plan.scan_sorted(dev)
     assert got.size == want.size and np.array_equal(got, want)
     assert int(plan.count(dev).item()) == want.size
+    if want.size > 7:   # a record buffer that is too small: the total is still reported, nothing written past the end
+        rec, cnt = plan.scan(dev, capacity=7)
+        assert int(cnt.item()) == want.size and rec.shape[0] == 7
+        assert np.array_equal(plan.scan_sorted(dev, capacity=7), want)      # grows and repeats
     lmax = m.lmax
     for _ in range(6):
         b = int(rng.integers(0, text.size))
