@@ -947,6 +947,19 @@ launch_sparse (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
   return ACM_GPU_OK;
 }
 
+/* the last sixteenth of the tiles [range_begin, range_end) becomes the dynamic pool (none for
+ * launches of a few tiles per wave); counters alternate from launch to launch (TileShare) */
+void
+set_tile_pool (ACMPlan *p, Launch &a, uint32_t waves) {
+  const uint32_t tiles = a.range_end - a.range_begin;
+  const uint32_t pool = tiles >= waves * 8 ? tiles / 16 : 0;
+  a.static_end = a.range_end - pool;
+  a.pool_class_tiles = (pool + POOL_CLASSES - 1) / POOL_CLASSES;
+  a.pool_ctr = p->d_pool_ctr + (p->launch_seq & 1) * POOL_CLASSES * POOL_CTR_STRIDE;
+  a.pool_reset = p->d_pool_ctr + ((p->launch_seq & 1) ^ 1) * POOL_CLASSES * POOL_CTR_STRIDE;
+  p->launch_seq++;
+}
+
 /* records of the hits parked by `regions_used` waves of the start-parallel / 4-gram kernels */
 void
 launch_expand_hits (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, hipStream_t st) {
@@ -977,6 +990,7 @@ launch_starts (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
   const uint32_t tiles = a.range_end - a.range_begin;
   if ((tiles + wpb - 1) / wpb < grid)
     grid = (tiles + wpb - 1) / wpb;
+  set_tile_pool (p, a, grid * wpb);
   void *items = COUNT_ONLY ? nullptr : p->d_items;
   uint32_t *fill = COUNT_ONLY ? nullptr : p->d_fill;
   void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
@@ -1008,6 +1022,7 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
   const uint32_t tiles = a.range_end - a.range_begin;
   if ((tiles + wpb - 1) / wpb < grid)
     grid = (tiles + wpb - 1) / wpb;
+  set_tile_pool (p, a, grid * wpb);
   void *items = COUNT_ONLY ? nullptr : p->d_items;
   uint32_t *fill = COUNT_ONLY ? nullptr : p->d_fill;
   void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };

@@ -71,8 +71,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   /* block b takes the tiles b, b + gridDim.x, ... (match density is rarely even along a text:
    * contiguous shares left two blocks of config 3 working 1 ms after all others had finished),
    * handed to its waves through the LDS counter */
-  const uint32_t ntiles = A.range_end - A.range_begin;
-  const uint32_t blk_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const TileShare share (A);
   const uint32_t last_blk = (A.n - 1) / 16;
   uint32_t qn1 = 0, qn2 = 0;
   unsigned long long counted = 0;
@@ -194,14 +193,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   };
 
   for (;;) {
-    uint32_t t = 0;
-    if (lane == 0)
-      t = atomicAdd (next_tile, 1u);
-    t = uniform (t);
-    if (t >= blk_tiles)
+    const uint32_t tile = share.next (next_tile, lane);
+    if (tile == NONE)
       break;
     DIAG (d_tiles++;)
-    const uint32_t g0 = (A.range_begin + t * gridDim.x + blockIdx.x) * K.R;
+    const uint32_t g0 = tile * K.R;
     uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
     for (uint32_t k = 0; k < K.R; k++) {
       const uint4 n3 = load_group (g0 + k + 4);

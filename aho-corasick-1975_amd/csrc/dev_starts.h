@@ -238,6 +238,45 @@ starts_root (const StartsK &K, uint32_t c) {
   return ST_SECOND;
 }
 
+/* Which tile a wave of the start-parallel / 4-gram kernels takes next.  Tiles [range_begin,
+ * static_end) go to the blocks interleaved (block b: b, b + gridDim.x, ...: match density is
+ * rarely even along a text, contiguous shares left two blocks of config 3 working 1 ms after all
+ * others), handed to the block's waves through an LDS counter; the last sixteenth, [static_end,
+ * range_end), is a pool in POOL_CLASSES parts drawn tile by tile through one global counter per
+ * part (Launch::pool_ctr, as in the dense kernel): the XCDs do not run at the same pace. */
+struct TileShare {
+  uint32_t begin, static_tiles, blk_tiles, cls_begin, cls_tiles;
+  unsigned int *cls_ctr;
+  __device__ __forceinline__
+  TileShare (const Launch &A) {
+    begin = A.range_begin;
+    static_tiles = A.static_end - A.range_begin;
+    blk_tiles = blockIdx.x < static_tiles ? (static_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t cls = blockIdx.x * POOL_CLASSES / gridDim.x;
+    cls_begin = A.static_end + cls * A.pool_class_tiles;
+    cls_tiles = cls_begin >= A.range_end ? 0 : (A.range_end - cls_begin < A.pool_class_tiles ? A.range_end - cls_begin : A.pool_class_tiles);
+    cls_ctr = A.pool_ctr + cls * POOL_CTR_STRIDE;
+    if (blockIdx.x == 0 && threadIdx.x < POOL_CLASSES)
+      A.pool_reset[threadIdx.x * POOL_CTR_STRIDE] = 0; /* the previous launch's counters */
+  }
+  /* wave-uniform tile index, NONE when there is nothing left */
+  __device__ __forceinline__ uint32_t
+  next (uint32_t *lds_counter, uint32_t lane) const {
+    uint32_t t = NONE;
+    if (lane == 0) {
+      const uint32_t i = atomicAdd (lds_counter, 1u);
+      if (i < blk_tiles)
+        t = begin + i * gridDim.x + blockIdx.x;
+      else if (cls_tiles) {
+        const uint32_t g = atomicAdd (cls_ctr, 1u);
+        if (g < cls_tiles)
+          t = cls_begin + g;
+      }
+    }
+    return uniform (t);
+  }
+};
+
 /* a start between the first and the second sieve */
 struct PendingStart {
   uint2 pair;     /* the child's first two edge symbols (load in flight) */
@@ -286,8 +325,7 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
   /* block b takes the tiles b, b + gridDim.x, ... (match density is rarely even along a text:
    * contiguous shares left two blocks of config 3 working 1 ms after all others had finished),
    * handed to its waves through the LDS counter */
-  const uint32_t ntiles = A.range_end - A.range_begin;
-  const uint32_t blk_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const TileShare share (A);
   const uint32_t last_blk = (uint32_t)(((uint64_t)A.n * sizeof (SYM) - 1) / 16);
   uint32_t qn = 0;
   unsigned long long counted = 0;
@@ -363,14 +401,11 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
   };
 
   for (;;) {
-    uint32_t t = 0;
-    if (lane == 0)
-      t = atomicAdd (next_tile, 1u);
-    t = uniform (t);
-    if (t >= blk_tiles)
+    const uint32_t tile = share.next (next_tile, lane);
+    if (tile == NONE)
       break;
     DIAG (d_tiles++;)
-    const uint32_t g0 = (A.range_begin + t * gridDim.x + blockIdx.x) * K.R;
+    const uint32_t g0 = tile * K.R;
     uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
     for (uint32_t k = 0; k < K.R; k += 4) {
       const uint32_t g = g0 + k;
