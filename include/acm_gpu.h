@@ -154,7 +154,11 @@ typedef struct {
 } ACMPlanInfo;
 
 /* Flattens `machine` and uploads the tables to `device`.  The plan is a snapshot: keywords
- * inserted later are not seen by it. */
+ * inserted later are not seen by it until acm_gpu_plan_update.
+ * A plan owns scratch buffers that its scans share (item regions, the running record count, the
+ * class-mapped / aligned copy of the text): scans of ONE plan must be issued from one host thread
+ * and on one stream at a time (consecutive scans on the same stream queue up as usual; for
+ * concurrent streams or threads make one plan each -- the tables are a few MB). */
 int acm_gpu_plan_create (ACMachine *machine, int device, ACMPlan **out);
 int acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out);
 /* acm_flatten_classes + acm_gpu_plan_create_flat: plan of a machine with a custom comparator over
