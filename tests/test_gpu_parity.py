@@ -637,3 +637,21 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
         sel = want[(want["end_pos"] >= b) & (want["end_pos"] < e)].copy()
         sel["end_pos"] += base - rb
         assert np.array_equal(got, sel), (kind, seed, b, e)
+
+
+@pytest.mark.parametrize("sym", [1, 4])
+def test_plan_of_an_empty_machine_and_its_first_keywords(torch_cuda, sym):
+    """A plan made before any keyword exists finds nothing (generic_test.c:70 asserts the same of
+    acm_match); acm_gpu_plan_update then takes it through its first keywords."""
+    dt = {1: np.uint8, 4: np.uint32}[sym]
+    m, o = build_pair([], sym)
+    text = (np.arange(5000) % 7 + 1).astype(dt)
+    dev = _dev(torch_cuda, text)
+    plan = m.plan(0)
+    assert plan.scan_sorted(dev).size == 0 and int(plan.count(dev).item()) == 0
+    for kw in ([3], [1, 2, 3], [7, 1], [2, 3, 4, 5, 6], [5]):
+        m.add_keyword(np.array(kw, dt))
+        o.add_keyword(np.array(kw, dt))
+        plan.update(m)
+        want = o.scan(text)
+        assert want.size > 0 and np.array_equal(plan.scan_sorted(dev), want)
