@@ -50,7 +50,7 @@ class FlatView(C.Structure):
     _fields_ = [(n, C.POINTER(C.c_uint32)) for n in ("row_ptr", "edge_sym", "edge_next", "fail", "depth", "nb_outputs",
                                                      "term_kw", "out_link", "depth_start", "kw_state")] + [
         ("class_map", C.POINTER(C.c_uint16)), ("edge_letter", C.POINTER(C.c_uint32)), ("class_entries", C.c_uint32),
-        ("n_classes", C.c_uint32)]
+        ("n_classes", C.c_uint32), ("keys64", C.POINTER(C.c_uint64)), ("n_keys64", C.c_uint32)]
 
 
 class PlanInfo(C.Structure):
@@ -221,6 +221,8 @@ class FlatTables:
         self.n_classes = int(v.n_classes)
         self.class_map = np.ctypeslib.as_array(v.class_map, shape=(v.class_entries,)).copy() if v.class_entries else None
         self.edge_letter = arr(v.edge_letter, ne) if v.class_entries else None
+        # 8-byte symbols: edge_sym = 1 + index into keys64 (the dictionary's distinct symbols, ascending)
+        self.keys64 = np.ctypeslib.as_array(v.keys64, shape=(v.n_keys64,)).copy() if v.n_keys64 else None
 
     def dense_rows(self, n_rows=None, entry_bytes=None):
         info = self.info
@@ -260,7 +262,7 @@ class FlatTables:
         n = C.c_uint32(0)
         L = lib()
         _check(L.acm_flat_keyword(self._h, keyword_id, None, 0, C.byref(n)), "acm_flat_keyword")
-        out = np.zeros(n.value, dtype={1: np.uint8, 2: np.uint16, 4: np.uint32}[sb])
+        out = np.zeros(n.value, dtype={1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[sb])
         _check(L.acm_flat_keyword(self._h, keyword_id, out.ctypes.data, n.value, C.byref(n)), "acm_flat_keyword")
         return out
 

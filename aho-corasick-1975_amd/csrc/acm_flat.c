@@ -21,6 +21,10 @@ struct ACMFlat {
   uint16_t *class_map;   /* [class_entries] symbol value -> class id; NULL for ACM_CMP_DEFAULT machines */
   uint32_t *edge_letter; /* [n_edges] the dictionary's own symbol on each edge */
   uint32_t class_entries, n_classes;
+  /* 8-byte symbols: edge_sym holds 1 + the rank of the symbol among the distinct symbols of the
+   * dictionary (0 is kept for every other symbol of a text); keys64 are those symbols, ascending */
+  uint64_t *keys64;
+  uint32_t n_keys64;
 };
 
 static uint32_t
@@ -30,6 +34,35 @@ symbol_value (const void *letter, uint32_t sym_bytes) {
   for (uint32_t i = 0; i < sym_bytes; i++)
     v |= (uint32_t)p[i] << (8 * i);
   return v;
+}
+
+static uint64_t
+symbol_value64 (const void *letter) {
+  const unsigned char *p = letter;
+  uint64_t v = 0;
+  for (uint32_t i = 0; i < 8; i++)
+    v |= (uint64_t)p[i] << (8 * i);
+  return v;
+}
+
+static int
+u64_cmp (const void *a, const void *b) {
+  const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x < y ? -1 : x > y;
+}
+
+/* 1 + rank of v among the n sorted keys (it is one of them) */
+static uint32_t
+key_rank1 (const uint64_t *keys, uint32_t n, uint64_t v) {
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (keys[mid] <= v)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo + 1;
 }
 
 struct row_item {
@@ -77,6 +110,7 @@ acm_flat_release (ACMFlat *f) {
   free (f->kw_state);
   free (f->class_map);
   free (f->edge_letter);
+  free (f->keys64);
   free (f);
 }
 
@@ -113,13 +147,36 @@ flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint3
   uint32_t head = 0, tail = 0, edges = 0, lmax = 0, nkw = 0, max_out = 0;
   order[tail++] = acm_internal_root (machine);
   newid[order[0]->id] = 0;
+  if (sym_bytes == 8) {
+    /* intern the symbols: a first walk collects the distinct ones (the kernels then see 4-byte
+     * ids; a text is mapped through the same table on the device before it is walked) */
+    uint64_t *keys = malloc ((size_t)(n ? n : 1) * sizeof *keys);
+    if (!keys)
+      goto nomem;
+    f->keys64 = keys;
+    uint32_t nk = 0;
+    for (uint32_t h = 0, t = 1; h < t; h++) {
+      struct _ac_state *st = order[h];
+      for (uint32_t i = 0; i < st->nkids; i++) {
+        keys[nk++] = symbol_value64 (st->kids[i]->letter);
+        order[t++] = st->kids[i];
+      }
+    }
+    qsort (keys, nk, sizeof *keys, u64_cmp);
+    uint32_t u = 0;
+    for (uint32_t i = 0; i < nk; i++)
+      if (i == 0 || keys[i] != keys[i - 1])
+        keys[u++] = keys[i];
+    f->n_keys64 = u;
+  }
   while (head < tail) {
     struct _ac_state *s = order[head];
     f->row_ptr[head] = edges;
     for (uint32_t i = 0; i < s->nkids; i++) {
       struct _ac_state *k = s->kids[i];
       newid[k->id] = tail;
-      f->edge_sym[edges] = symbol_value (k->letter, sym_bytes);
+      f->edge_sym[edges] = sym_bytes == 8 ? key_rank1 (f->keys64, f->n_keys64, symbol_value64 (k->letter))
+                                          : symbol_value (k->letter, sym_bytes);
       if (class_map) {
         f->edge_letter[edges] = f->edge_sym[edges];
         f->edge_sym[edges] = class_map[f->edge_sym[edges]];
@@ -345,6 +402,8 @@ acm_flat_view (const ACMFlat *f, ACMFlatView *v) {
   v->edge_letter = f->edge_letter;
   v->class_entries = f->class_entries;
   v->n_classes = f->n_classes;
+  v->keys64 = f->keys64;
+  v->n_keys64 = f->n_keys64;
 }
 
 /* Failure-resolved rows.  Row 0: goto or stay at the root.  Row s > 0: copy of row f(s) (already
@@ -429,6 +488,8 @@ int
 acm_flat_to_blob (const ACMFlat *f, void *out, size_t capacity) {
   if (!f || !out || capacity < acm_flat_blob_bytes (f))
     return ACM_GPU_E_ARG;
+  if (f->keys64)
+    return ACM_GPU_E_INELIGIBLE; /* version 1 of the format has no place for the symbol table of 8-byte alphabets */
   const ACMFlatInfo *in = &f->info;
   unsigned char *b = out, *p = b + BLOB_HEADER;
 #define PUT(arr, cnt)                                                                              \
@@ -714,6 +775,27 @@ acm_flat_keyword (const ACMFlat *f, uint32_t kw_id, void *symbols, uint32_t capa
   const uint32_t len = f->depth[s], sb = f->info.sym_bytes;
   if (length)
     *length = len;
+  if (f->keys64) { /* 8-byte symbols: edge_sym is 1 + the rank in keys64 */
+    for (uint32_t d = len; d > 0; d--) {
+      const uint32_t e = s - 1;
+      if (d - 1 < capacity) {
+        const uint64_t v = f->keys64[f->edge_sym[e] - 1];
+        unsigned char *o = (unsigned char *)symbols + (size_t)(d - 1) * 8;
+        for (uint32_t i = 0; i < 8; i++)
+          o[i] = (unsigned char)(v >> (8 * i));
+      }
+      uint32_t lo = 0, hi = f->info.n_states;
+      while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (f->row_ptr[mid] <= e)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      s = lo;
+    }
+    return ACM_GPU_OK;
+  }
   for (uint32_t d = len; d > 0; d--) {
     /* parent of s: the row that contains edge s - 1 */
     const uint32_t e = s - 1;

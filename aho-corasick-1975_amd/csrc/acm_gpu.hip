@@ -205,6 +205,11 @@ struct ACMPlan {
   uint32_t launch_seq = 0;
   /* comparator-class plans: the text is mapped to class ids into d_remap before every scan */
   uint16_t *d_classlut = nullptr;
+  /* 8-byte symbols: hash table {key, id} of the dictionary's symbols; the text is interned to
+   * 4-byte ids into d_remap and finfo.sym_bytes is 4 (what the kernels walk) */
+  uint4 *d_intern = nullptr;
+  uint32_t intern_mask = 0;
+  uint32_t text_sym_bytes = 0; /* symbol size of the caller's text (== finfo.sym_bytes unless interned) */
   void *d_remap = nullptr;
   size_t remap_bytes = 0;
   uint32_t regions = 0, region_items = 0;
@@ -326,12 +331,19 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   acm_flat_view (flat, &fv);
   if (fi.lmax >= (1u << 24))
     return ACM_GPU_E_INELIGIBLE;
+  const bool interned = fi.sym_bytes == 8;
+  if (interned) {
+    if (!fv.keys64 && fi.n_edges)
+      return ACM_GPU_E_ARG;
+    fi.sym_bytes = 4; /* from here on: a machine over 4-byte ids */
+  }
 
   ACMPlan *p = new (std::nothrow) ACMPlan ();
   if (!p)
     return ACM_GPU_E_NOMEM;
   p->device = device;
   p->finfo = fi;
+  p->text_sym_bytes = interned ? 8 : fi.sym_bytes;
   p->cu_count = prop.multiProcessorCount;
 
   if (const char *e = getenv ("ACM_GPU_SEGMENT_LOG2")) {
@@ -768,6 +780,34 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       HIP_TRY (hipFuncSetAttribute (dense_kernel_ptr (entry_bytes, p->chunk, p->streams, co != 0),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)I.lds_bytes));
   }
+  if (interned) {
+    uint32_t cap = 16;
+    while (cap < 2 * (fv.n_keys64 + 1))
+      cap <<= 1;
+    std::vector<uint32_t> tab ((size_t)cap * 4, 0);
+    auto mix = [] (uint64_t x) {
+      x ^= x >> 30;
+      x *= 0xBF58476D1CE4E5B9ull;
+      x ^= x >> 27;
+      x *= 0x94D049BB133111EBull;
+      return x ^ (x >> 31);
+    };
+    for (uint32_t k = 0; k < fv.n_keys64; k++) {
+      const uint64_t key = fv.keys64[k];
+      uint32_t h = (uint32_t)mix (key) & (cap - 1);
+      while (tab[4 * (size_t)h + 2])
+        h = (h + 1) & (cap - 1);
+      tab[4 * (size_t)h] = (uint32_t)key;
+      tab[4 * (size_t)h + 1] = (uint32_t)(key >> 32);
+      tab[4 * (size_t)h + 2] = k + 1;
+    }
+    if (hipMalloc (reinterpret_cast<void **> (&p->d_intern), (size_t)cap * 16) != hipSuccess ||
+        hipMemcpy (p->d_intern, tab.data (), (size_t)cap * 16, hipMemcpyHostToDevice) != hipSuccess) {
+      acm_gpu_plan_destroy (p);
+      return ACM_GPU_E_NOMEM;
+    }
+    p->intern_mask = cap - 1;
+  }
   if (fv.class_map) {
     /* 65,536 entries either way: 2-byte symbols directly, bytes in pairs (see classmap_kernel) */
     std::vector<uint16_t> lut (65536);
@@ -838,6 +878,8 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
       (void)hipFree (plan->mir->d_patches);
     delete plan->mir;
   }
+  if (plan->d_intern)
+    (void)hipFree (plan->d_intern);
   if (plan->d_classlut)
     (void)hipFree (plan->d_classlut);
   if (plan->d_remap)
@@ -1427,7 +1469,20 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     if (rc)
       return rc;
   }
-  if (p->d_classlut) {
+  if (p->d_intern) {
+    /* 8-byte symbols: the kernels walk the 4-byte ids of the text */
+    if (reinterpret_cast<uintptr_t> (d_text) & 7)
+      return ACM_GPU_E_ARG;
+    int rc = ensure_remap_buffer (p, (size_t)n * 4, st);
+    if (rc)
+      return rc;
+    const uint64_t want_blocks = (n + 255) / 256;
+    const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)p->cu_count * 32 ? want_blocks : (uint64_t)p->cu_count * 32);
+    hipLaunchKernelGGL (intern_kernel, dim3 (grid), dim3 (256), 0, st, static_cast<const uint64_t *> (d_text),
+                        static_cast<uint32_t *> (p->d_remap), n, p->d_intern, p->intern_mask);
+    HIP_TRY (hipGetLastError ());
+    d_text = p->d_remap;
+  } else if (p->d_classlut) {
     /* comparator-class plan: walk the class ids of the text (our own, aligned, copy) */
     int rc = classmap_text (p, d_text, n, st);
     if (rc)
@@ -1555,7 +1610,7 @@ acm_gpu_stream_open (ACMPlan *plan, uint64_t max_piece_symbols, uint64_t record_
   if (!s)
     return ACM_GPU_E_NOMEM;
   s->plan = plan;
-  s->sb = plan->finfo.sym_bytes;
+  s->sb = plan->text_sym_bytes; /* of the caller's text (8-byte symbols are interned inside the scan) */
   s->halo = plan->finfo.lmax > 1 ? (((uint64_t)plan->finfo.lmax - 1 + 15) / 16) * 16 : 0;
   s->max_piece = (max_piece_symbols + 15) / 16 * 16;
   s->capacity = record_capacity;
@@ -1739,7 +1794,7 @@ acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint64_t
   if (!plan || !n_found || (n_symbols && !text) || (capacity && !records))
     return ACM_GPU_E_ARG;
   HIP_TRY (hipSetDevice (plan->device));
-  const size_t tbytes = (size_t)n_symbols * plan->finfo.sym_bytes;
+  const size_t tbytes = (size_t)n_symbols * plan->text_sym_bytes;
   void *d_text = nullptr, *d_rec = nullptr, *d_tmp = nullptr;
   uint64_t *d_count = nullptr;
   int rc = ACM_GPU_OK;

@@ -81,7 +81,7 @@ acm_internal_symbol_bytes (const ACMachine *m, uint32_t *sym_bytes) {
   if (m->cmp != ACM_CMP_DEFAULT || !m->cmp_arg)
     return ACM_GPU_E_INELIGIBLE;
   size_t sz = *(const size_t *)m->cmp_arg;
-  if (sz != 1 && sz != 2 && sz != 4)
+  if (sz != 1 && sz != 2 && sz != 4 && sz != 8)
     return ACM_GPU_E_INELIGIBLE;
   *sym_bytes = (uint32_t)sz;
   return ACM_GPU_OK;

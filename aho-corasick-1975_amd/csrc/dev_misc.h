@@ -33,6 +33,38 @@ classmap_tail_kernel (const SYM *__restrict__ in, SYM *__restrict__ out, uint64_
     out[i] = (SYM)lut[in[i]]; /* a byte v indexes entry (0 << 8) | v: class(v) in its low byte */
 }
 
+/* ------------------------------------------------------------------ 8-byte symbols
+ * The dictionary's distinct symbols get the ids 1 .. K (ACMFlatView::keys64), every other symbol
+ * of a text the id 0; the text is mapped to 4-byte ids through an open-addressing hash table
+ * {key, id} (at most half full, linear probing) and walked by the kernels for 4-byte symbols. */
+__device__ __forceinline__ uint64_t
+intern_hash (uint64_t x) { /* splitmix64 finaliser */
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ void
+intern_kernel (const uint64_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n, const uint4 *__restrict__ table, uint32_t mask) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t k = in[i];
+    uint32_t h = (uint32_t)intern_hash (k) & mask, id = 0;
+    for (;;) {
+      const uint4 slot = table[h]; /* {key lo, key hi, id (0: empty slot), -} */
+      if (slot.z == 0)
+        break;
+      if (slot.x == (uint32_t)k && slot.y == (uint32_t)(k >> 32)) {
+        id = slot.z;
+        break;
+      }
+      h = (h + 1) & mask;
+    }
+    out[i] = id;
+  }
+}
+
 /* ------------------------------------------------------------------ incremental updates
  * word patches for the tables of the start-parallel kernel: {table, index, value, -} */
 struct PatchTables {

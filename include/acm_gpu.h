@@ -39,7 +39,7 @@ typedef struct {
 
 enum {
   ACM_GPU_OK = 0,
-  ACM_GPU_E_INELIGIBLE = -1, /* comparator is not ACM_CMP_DEFAULT, or symbol size not 1/2/4 bytes */
+  ACM_GPU_E_INELIGIBLE = -1, /* comparator is not ACM_CMP_DEFAULT, or symbol size not 1/2/4/8 bytes */
   ACM_GPU_E_NODEVICE = -2,   /* no usable HIP device */
   ACM_GPU_E_HIP = -3,        /* a HIP call failed (message on stderr) */
   ACM_GPU_E_OVERFLOW = -4,   /* more matches than `capacity`; the count output holds the number needed */
@@ -67,7 +67,7 @@ int acm_get_keyword (const ACMachine *machine, uint32_t keyword_id, MatchHolder 
 typedef struct ACMFlat ACMFlat;
 
 typedef struct {
-  uint32_t sym_bytes;   /* 1, 2 or 4 */
+  uint32_t sym_bytes;   /* 1, 2, 4 or 8 */
   uint32_t n_states;
   uint32_t n_keywords;
   uint32_t n_edges;     /* = n_states - 1 */
@@ -94,6 +94,10 @@ typedef struct {
   const uint32_t *edge_letter; /* [n_edges] the dictionary's own symbol on each edge (what MatchHolder.letters[] point at) */
   uint32_t class_entries;      /* 256 or 65536 */
   uint32_t n_classes;
+  /* 8-byte symbols only, else NULL / 0: the distinct symbols of the dictionary, ascending; edge_sym
+   * holds 1 + the index into this table (0 stands for every other symbol a text may hold) */
+  const uint64_t *keys64;
+  uint32_t n_keys64;
 } ACMFlatView;
 
 int acm_flatten (ACMachine *machine, ACMFlat **out);

@@ -70,11 +70,18 @@ def test_empty_machine_and_ineligible_symbol_size():
     f = m.flatten()
     assert f.info.n_states == 1 and f.info.n_edges == 0 and f.info.lmax == 0
     assert flatwalk.walk_csr(f, b"anything").size == 0
-    m8 = acm.Machine(8)
-    m8.add_keyword(np.array([1, 2], np.uint64))
-    with pytest.raises(acm.ACMError) as e:
-        m8.flatten()
-    assert e.value.code == -1
+    # symbol sizes other than 1, 2, 4, 8 bytes stay on the per-symbol API (raw C API: 3-byte symbols)
+    import ctypes as C
+    L = acm.lib()
+    size3 = C.c_size_t(3)
+    m3 = L.acm_create(C.c_void_p.in_dll(L, "ACM_CMP_DEFAULT"), C.cast(C.pointer(size3), C.c_void_p), None)
+    letters = C.create_string_buffer(b"abcdef")
+    cur = C.c_void_p(L.acm_initiate(m3))
+    L.acm_insert_letter_of_keyword(C.byref(cur), C.cast(letters, C.c_void_p))
+    L.acm_insert_end_of_keyword(C.byref(cur), None, None)
+    flat = C.c_void_p()
+    assert L.acm_flatten(m3, C.byref(flat)) == -1
+    L.acm_release(m3)
 
 
 def test_emit_from_and_pos_base_on_walkers():
@@ -114,3 +121,36 @@ def test_synthetic_64MiB_digest_matches_survey():
     assert cnt == 35453 and dig == 0x75c631ca92f2fd08
     got = flatwalk.walk_dense(m.flatten(), text)
     assert got.size == 35453 and po.digest(got) == 0x75c631ca92f2fd08
+
+
+def test_eight_byte_symbols_are_interned():
+    """ACM_CMP_DEFAULT over 8-byte symbols: the flat tables carry 1 + rank of each symbol among the
+    dictionary's distinct symbols (keys64); a text interned the same way (0 = any other symbol)
+    walks to the oracle's records; spellings come back as the original 8-byte symbols."""
+    rng = np.random.default_rng(3)
+    vocab = rng.integers(0, 1 << 63, size=40, dtype=np.uint64) | np.uint64(1 << 40)
+    kws = [vocab[rng.integers(0, 40, size=rng.integers(1, 6))] for _ in range(60)]
+    m, o = build_pair(kws, 8)
+    flat = m.flatten()
+    assert flat.info.sym_bytes == 8 and flat.keys64 is not None
+    assert np.all(np.diff(flat.keys64.astype(object)) > 0)
+    used = np.unique(np.concatenate(kws))
+    assert np.array_equal(flat.keys64, used)
+    assert flat.edge_sym.min() >= 1 and flat.edge_sym.max() <= used.size
+    text = np.concatenate([vocab[rng.integers(0, 40, size=3000)], rng.integers(0, 1 << 62, size=500, dtype=np.uint64)])
+    rng.shuffle(text)
+    ids = np.zeros(text.size, np.uint64)   # (the CPU walker reads symbols of the tables' width: 8 bytes)
+    pos = np.searchsorted(flat.keys64, text)
+    hit = (pos < flat.keys64.size) & (flat.keys64[np.minimum(pos, flat.keys64.size - 1)] == text)
+    ids[hit] = pos[hit].astype(np.uint64) + 1
+    want = o.scan(text)
+    assert want.size > 20
+    assert np.array_equal(flatwalk.walk_csr(flat, ids), want)
+    seen = []
+    for kw in kws:
+        if kw.tolist() not in seen:
+            seen.append(kw.tolist())
+    for k, spelled in enumerate(seen):
+        assert flat.keyword(k).tolist() == spelled
+    with pytest.raises(RuntimeError):
+        flat.to_bytes()                    # version 1 of the blob format has no 8-byte symbol table

@@ -655,3 +655,45 @@ def test_plan_of_an_empty_machine_and_its_first_keywords(torch_cuda, sym):
         plan.update(m)
         want = o.scan(text)
         assert want.size > 0 and np.array_equal(plan.scan_sorted(dev), want)
+
+
+def test_eight_byte_symbols_on_the_gpu(torch_cuda):
+    """ACM_CMP_DEFAULT over 8-byte symbols (sizes 1, 2, 4, 8): the device interns the
+    text through a hash table of the dictionary's symbols and walks 4-byte ids."""
+    rng = np.random.default_rng(8)
+    vocab = rng.integers(0, 1 << 63, size=3000, dtype=np.uint64)
+    kws = [vocab[rng.integers(0, vocab.size, size=rng.integers(1, 7))] for _ in range(1500)]
+    m, o = build_pair(kws, 8)
+    text = vocab[rng.integers(0, vocab.size, size=200003)]
+    noise = rng.integers(0, text.size, size=20000)
+    text[noise] = rng.integers(0, 1 << 63, size=noise.size, dtype=np.uint64)      # symbols the dictionary has never seen
+    for _ in range(300):
+        w = kws[int(rng.integers(0, len(kws)))]
+        at = int(rng.integers(0, text.size - w.size))
+        text[at:at + w.size] = w
+    plan = m.plan(0)
+    assert plan.info.kernel == 4
+    want = o.scan(text)
+    assert want.size > 300
+    dev = _dev(torch_cuda, text)
+    got = plan.scan_sorted(dev)
+    assert got.size == want.size and np.array_equal(got, want)
+    assert int(plan.count(dev).item()) == want.size
+    for b, e in ((0, 1), (3, 70001), (100000, text.size)):
+        rb = max(b - (m.lmax - 1), 0)
+        got = plan.scan_sorted(dev[rb:e], emit_from=b - rb, pos_base=rb)
+        assert np.array_equal(got, want[(want["end_pos"] >= b) & (want["end_pos"] < e)])
+    # host-buffer path and streaming take 8-byte symbols too
+    assert np.array_equal(plan.scan_host(text), want)
+    st = plan.stream(max_piece_symbols=30000, record_capacity=1 << 16)
+    for off in range(0, text.size, 30000):
+        st.feed(text[off:off + 30000])
+    assert np.array_equal(st.finish(), want)
+    st.close()
+    # new keywords: the plan is rebuilt behind the same handle (new symbols get new ids)
+    extra = [np.array([text[5], text[6], text[7]], np.uint64), rng.integers(0, 1 << 63, size=2, dtype=np.uint64)]
+    for kw in extra:
+        m.add_keyword(kw)
+        o.add_keyword(kw)
+    plan.update(m)
+    assert np.array_equal(plan.scan_sorted(dev), o.scan(text))
