@@ -451,11 +451,11 @@ acm_flat_dense_rows (const ACMFlat *f, uint32_t n_rows, uint32_t entry_bytes, vo
  *
  *   header, 80 bytes: "AC75FLAT" | u32 version (1) | u32 0x01020304 (byte-order probe) |
  *                     ACMFlatInfo (9 x u32) | u32 class-table entries (0, 256 or 65536) |
- *                     u64 payload bytes | u64 FNV-1a-64 of payload | u64 0
+ *                     u64 payload bytes | u64 FNV-1a-64 of payload | u64 number of 8-byte symbols (keys64)
  *   payload, u32 arrays in this order: row_ptr[n+1] edge_sym[E] edge_next[E] fail[n] depth[n]
  *                     nb_outputs[n] term_kw[n] out_link[n] depth_start[lmax+2] kw_state[K]
  *                     and for comparator-class machines: class_map (u16, entries / 2 words)
- *                     edge_letter[E]
+ *                     edge_letter[E]; for 8-byte symbols: keys64 (2 words each)
  *
  * Loading trusts nothing: the goto function (row_ptr, edge_sym, term_kw) is checked for shape,
  * every other array -- the failure function included -- is recomputed from it and compared.  A
@@ -474,22 +474,22 @@ fnv1a64 (const unsigned char *p, size_t n) {
 }
 
 static size_t
-blob_payload_words (const ACMFlatInfo *in, uint32_t class_entries) {
+blob_payload_words (const ACMFlatInfo *in, uint32_t class_entries, uint64_t n_keys64) {
   const size_t n = in->n_states, e = in->n_edges;
-  return (n + 1) + 2 * e + 5 * n + ((size_t)in->lmax + 2) + in->n_keywords + (class_entries ? class_entries / 2 + e : 0);
+  return (n + 1) + 2 * e + 5 * n + ((size_t)in->lmax + 2) + in->n_keywords + (class_entries ? class_entries / 2 + e : 0) +
+         2 * (size_t)n_keys64;
 }
 
 size_t
 acm_flat_blob_bytes (const ACMFlat *f) {
-  return f ? BLOB_HEADER + 4 * blob_payload_words (&f->info, f->class_entries) : 0;
+  return f ? BLOB_HEADER + 4 * blob_payload_words (&f->info, f->class_entries, f->n_keys64) : 0;
 }
 
 int
 acm_flat_to_blob (const ACMFlat *f, void *out, size_t capacity) {
   if (!f || !out || capacity < acm_flat_blob_bytes (f))
     return ACM_GPU_E_ARG;
-  if (f->keys64)
-    return ACM_GPU_E_INELIGIBLE; /* version 1 of the format has no place for the symbol table of 8-byte alphabets */
+
   const ACMFlatInfo *in = &f->info;
   unsigned char *b = out, *p = b + BLOB_HEADER;
 #define PUT(arr, cnt)                                                                              \
@@ -511,11 +511,13 @@ acm_flat_to_blob (const ACMFlat *f, void *out, size_t capacity) {
     PUT (f->class_map, f->class_entries / 2);
     PUT (f->edge_letter, in->n_edges);
   }
+  if (f->n_keys64)
+    PUT (f->keys64, 2 * (size_t)f->n_keys64);
 #undef PUT
   const uint64_t payload = (uint64_t)(p - (b + BLOB_HEADER));
   const uint64_t sum = fnv1a64 (b + BLOB_HEADER, (size_t)payload);
   const uint32_t version = BLOB_VERSION, probe = 0x01020304u, zero = f->class_entries;
-  const uint64_t zero64 = 0;
+  const uint64_t zero64 = f->n_keys64;
   memcpy (b, BLOB_MAGIC, 8);
   memcpy (b + 8, &version, 4);
   memcpy (b + 12, &probe, 4);
@@ -556,16 +558,20 @@ acm_flat_from_blob (const void *blob, size_t bytes, ACMFlat **out) {
   memcpy (&probe, b + 12, 4);
   memcpy (&in, b + 16, sizeof in);
   memcpy (&class_entries, b + 52, 4);
+  uint64_t n_keys64;
+  memcpy (&n_keys64, b + 72, 8);
   memcpy (&payload, b + 56, 8);
   memcpy (&sum, b + 64, 8);
   if (version != BLOB_VERSION || probe != 0x01020304u)
     return ACM_GPU_E_FORMAT;
   if (in.n_states == 0 || in.n_edges != in.n_states - 1 || in.n_keywords > in.n_states ||
-      in.lmax >= in.n_states + 1 || (in.sym_bytes != 1 && in.sym_bytes != 2 && in.sym_bytes != 4))
+      in.lmax >= in.n_states + 1 || (in.sym_bytes != 1 && in.sym_bytes != 2 && in.sym_bytes != 4 && in.sym_bytes != 8))
+    return ACM_GPU_E_FORMAT;
+  if (n_keys64 > in.n_edges || (in.sym_bytes != 8 && n_keys64) || (in.sym_bytes == 8 && (n_keys64 != 0) != (in.n_edges != 0)))
     return ACM_GPU_E_FORMAT;
   if (class_entries != 0 && !(class_entries == 256 && in.sym_bytes == 1) && !(class_entries == 65536 && in.sym_bytes == 2))
     return ACM_GPU_E_FORMAT;
-  if (payload != 4ull * blob_payload_words (&in, class_entries) || bytes - BLOB_HEADER < payload ||
+  if (payload != 4ull * blob_payload_words (&in, class_entries, n_keys64) || bytes - BLOB_HEADER < payload ||
       fnv1a64 (b + BLOB_HEADER, (size_t)payload) != sum)
     return ACM_GPU_E_FORMAT;
 
@@ -604,6 +610,15 @@ acm_flat_from_blob (const void *blob, size_t bytes, ACMFlat **out) {
     p += (size_t)class_entries * 2;
     GET (edge_letter, E);
   }
+  if (n_keys64) {
+    f->keys64 = malloc ((size_t)n_keys64 * 8);
+    if (!f->keys64)
+      bad = 1;
+    else
+      memcpy (f->keys64, p, (size_t)n_keys64 * 8);
+    p += (size_t)n_keys64 * 8;
+    f->n_keys64 = (uint32_t)n_keys64;
+  }
 #undef GET
   if (bad) {
     acm_flat_release (f);
@@ -616,11 +631,13 @@ acm_flat_from_blob (const void *blob, size_t bytes, ACMFlat **out) {
   int ok = f->row_ptr[0] == 0 && f->row_ptr[n] == E;
   for (uint32_t s = 0; ok && s < n; s++)
     ok = f->row_ptr[s] <= f->row_ptr[s + 1] && f->row_ptr[s + 1] <= E;
-  const uint64_t sym_limit = in.sym_bytes == 4 ? (1ull << 32) : (1ull << (8 * in.sym_bytes));
+  const uint64_t sym_limit = in.sym_bytes == 8 ? n_keys64 + 1 : (in.sym_bytes == 4 ? (1ull << 32) : (1ull << (8 * in.sym_bytes)));
+  for (uint64_t k = 1; ok && k < n_keys64; k++) /* 8-byte symbols: strictly ascending table, ids from 1 */
+    ok = f->keys64[k - 1] < f->keys64[k];
   uint32_t lo = UINT32_MAX, hi = 0;
   for (uint32_t s = 0; ok && s < n; s++)
     for (uint32_t e = f->row_ptr[s]; ok && e < f->row_ptr[s + 1]; e++) {
-      ok = f->edge_next[e] == e + 1 && f->edge_sym[e] < sym_limit &&
+      ok = f->edge_next[e] == e + 1 && f->edge_sym[e] < sym_limit && (in.sym_bytes != 8 || f->edge_sym[e] >= 1) &&
            (e == f->row_ptr[s] || f->edge_sym[e - 1] < f->edge_sym[e]);
       if (f->edge_sym[e] < lo)
         lo = f->edge_sym[e];

@@ -152,5 +152,13 @@ def test_eight_byte_symbols_are_interned():
             seen.append(kw.tolist())
     for k, spelled in enumerate(seen):
         assert flat.keyword(k).tolist() == spelled
+    # blob round trip with the symbol table
+    from aho_corasick_1975_amd import binding
+    back = binding.FlatTables.from_bytes(flat.to_bytes())
+    assert np.array_equal(back.keys64, flat.keys64) and np.array_equal(back.edge_sym, flat.edge_sym)
+    assert back.keyword(0).tolist() == seen[0]
+    blob = bytearray(flat.to_bytes())
+    blob[-8:] = blob[-16:-8]                # last two symbols equal: not ascending
+    from tests.test_flat_blob import refnv
     with pytest.raises(RuntimeError):
-        flat.to_bytes()                    # version 1 of the blob format has no 8-byte symbol table
+        binding.FlatTables.from_bytes(refnv(bytes(blob)))
