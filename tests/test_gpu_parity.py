@@ -2,6 +2,8 @@
 caller loop on the same inputs -- bit-exact records in canonical order."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -583,7 +585,7 @@ def _random_case(rng, kind):
         text = rng.integers(96, 97 + span + 1, size=int(rng.integers(50000, 400000))).astype(np.uint8)
         return kws, text, 1, ({"ACM_GPU_GRAM": "0"} if kind == "sticky" else {})
     if kind == "short":             # > 32768 states but keywords shorter than 4: not eligible for the 4-gram kernel
-        kws = [rng.integers(97, 123, size=rng.integers(1, 12)).astype(np.uint8) for _ in range(int(rng.integers(7000, 9000)))]
+        kws = [rng.integers(97, 123, size=rng.integers(1, 12)).astype(np.uint8) for _ in range(int(rng.integers(10000, 12000)))]
         text = rng.integers(97, 123, size=int(rng.integers(50000, 300000))).astype(np.uint8)
         return kws, text, 1, {}
     sym = 2 if kind.endswith("16") else 4
@@ -595,7 +597,7 @@ def _random_case(rng, kind):
 
 
 @pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "gram", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
-                                       for s in range(3)])
+                                       for s in range(int(os.environ.get("ACM_SOAK_SEEDS", "3")))])   # ACM_SOAK_SEEDS=14: a soak run
 def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed):
     """Random dictionaries and texts through every kernel family; whole scans, count-only scans and
     random shards (emit_from, pos_base, odd offsets and lengths) against the oracle."""
