@@ -1,7 +1,6 @@
 """GPU parity: the HIP bulk scan (through the C ABI of include/acm_gpu.h) against the CPU oracle's
 caller loop on the same inputs -- bit-exact records in canonical order."""
 import ctypes as C
-
 import os
 
 import numpy as np
