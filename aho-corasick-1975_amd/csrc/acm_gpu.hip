@@ -1128,6 +1128,8 @@ ensure_item_buffer (ACMPlan *p, uint64_t n, uint32_t symbols_per_item = 256) {
   if (hipMalloc (reinterpret_cast<void **> (&p->d_fill), (size_t)regions * 4) != hipSuccess)
     return ACM_GPU_E_NOMEM;
   HIP_TRY (hipMemset (p->d_fill, 0, (size_t)regions * 4));
+  /* the memset runs on the null stream; the scans may run on streams that do not wait for it */
+  HIP_TRY (hipDeviceSynchronize ());
   p->regions = regions;
   p->region_items = (uint32_t)per;
   return ACM_GPU_OK;
@@ -1624,8 +1626,12 @@ acm_gpu_stream_open (ACMPlan *plan, uint64_t max_piece_symbols, uint64_t record_
     ok = hipEventCreateWithFlags (&s->copied[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags (&s->scanned[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags (&s->tail_read[i], hipEventDisableTiming) == hipSuccess;
-  /* a stream owns the plan's running total while it is open: start from zero */
-  ok = ok && hipMemset (plan->d_total, 0, 8) == hipSuccess;
+  /* a stream owns the plan's running total while it is open: start from zero.  Earlier scans of
+   * the plan (on whatever stream) must have drained, and the memset (null stream) must have landed
+   * before the stream's own non-blocking streams touch the total: without the waits a warm
+   * process lost the first piece's count now and then */
+  ok = ok && hipDeviceSynchronize () == hipSuccess && hipMemset (plan->d_total, 0, 8) == hipSuccess &&
+       hipDeviceSynchronize () == hipSuccess;
   if (!ok) {
     acm_gpu_stream_close (s);
     return ACM_GPU_E_NOMEM;
@@ -1722,6 +1728,7 @@ acm_gpu_stream_close (ACMStream *s) {
   if (s->compute)
     (void)hipStreamSynchronize (s->compute);
   (void)hipMemset (s->plan->d_total, 0, 8); /* hand the plan back with a clean running total */
+  (void)hipDeviceSynchronize ();
   for (int i = 0; i < 2; i++) {
     if (s->slot[i]) (void)hipFree (s->slot[i]);
     if (s->copied[i]) (void)hipEventDestroy (s->copied[i]);

@@ -627,6 +627,17 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
         rec, cnt = plan.scan(dev, capacity=7)
         assert int(cnt.item()) == want.size and rec.shape[0] == 7
         assert np.array_equal(plan.scan_sorted(dev, capacity=7), want)      # grows and repeats
+    # the same text fed to a stream in pieces of random sizes
+    piece_max = int(rng.integers(1000, 60000))
+    stream = plan.stream(max_piece_symbols=piece_max, record_capacity=max(want.size, 1) + 16)
+    off = 0
+    while off < text.size:
+        step = int(rng.integers(1, piece_max + 1))
+        stream.feed(text[off:off + step])
+        off += step
+    got = stream.finish()
+    stream.close()
+    assert got.size == want.size and np.array_equal(got, want)
     lmax = m.lmax
     for _ in range(6):
         b = int(rng.integers(0, text.size))
