@@ -477,12 +477,13 @@ def test_interleaved_classes_and_u16_on_the_gpu(torch_cuda, kat):
     assert np.array_equal(plan16.scan_sorted(_dev(torch_cuda, text16)[1:]), o16.scan(text16[1:]))
 
 
-def test_incremental_updates_of_a_start_parallel_plan(torch_cuda):
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ACM_SOAK_SEEDS", "1"))))
+def test_incremental_updates_of_a_start_parallel_plan(torch_cuda, seed):
     """keywords added while the plan is in use (reference README.md:352-356,
     generic_test.c:214-229).  uint32 symbols: the plan is edited in place (a few table words per
     keyword, written in front of the next scan); after every batch the records equal the oracle's."""
-    rng = np.random.default_rng(11)
-    V = 5000
+    rng = np.random.default_rng(11 + seed)
+    V = 5000 if seed == 0 else int(rng.integers(30, 40000))
     def word(lo, hi):
         return rng.integers(0, V, size=rng.integers(lo, hi)).astype(np.uint32)
     base = [word(2, 6) for _ in range(400)]
@@ -514,6 +515,12 @@ def test_incremental_updates_of_a_start_parallel_plan(torch_cuda):
         if step % 3 == 0:
             assert int(plan.count(dev).item()) == want.size
             assert np.array_equal(plan.scan_sorted(dev[1:]), o.scan(text[1:]))      # unaligned buffer: aligned copy inside
+        if step % 4 == 1:                                                            # and a stream on the edited plan
+            st = plan.stream(max_piece_symbols=50000, record_capacity=want.size + 16)
+            for off in range(0, text.size, 50000):
+                st.feed(text[off:off + 50000])
+            assert np.array_equal(st.finish(), want)
+            st.close()
         step += 1
     # the edited plan equals one built from scratch
     assert np.array_equal(m.plan(0).scan_sorted(dev), plan.scan_sorted(dev))
