@@ -634,6 +634,11 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
         rec, cnt = plan.scan(dev, capacity=7)
         assert int(cnt.item()) == want.size and rec.shape[0] == 7
         assert np.array_equal(plan.scan_sorted(dev, capacity=7), want)      # grows and repeats
+    # host buffers in, records out: acm_scan on the machine (its own cached plan) and on the plan
+    head = text[:min(text.size, 40000)]
+    want_head = want[want["end_pos"] < head.size]
+    assert np.array_equal(m.scan_host(head), want_head)
+    assert np.array_equal(plan.scan_host(head), want_head)
     # the same text fed to a stream in pieces of random sizes
     piece_max = int(rng.integers(1000, 60000))
     stream = plan.stream(max_piece_symbols=piece_max, record_capacity=max(want.size, 1) + 16)
