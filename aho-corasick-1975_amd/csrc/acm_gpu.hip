@@ -1117,6 +1117,8 @@ ensure_item_buffer (ACMPlan *p, uint64_t n, uint32_t symbols_per_item = 256) {
     per = 1u << 20;
   if (p->d_items && p->regions == regions && p->region_items >= per)
     return ACM_GPU_OK;
+  if (p->d_items || p->d_fill)
+    HIP_TRY (hipDeviceSynchronize ()); /* earlier scans (pieces of a stream) may still be parking items */
   if (p->d_items)
     HIP_TRY (hipFree (p->d_items));
   if (p->d_fill)
