@@ -590,6 +590,12 @@ def _random_case(rng, kind):
         kws = [rng.integers(97, 97 + span, size=rng.integers(4, 13)).astype(np.uint8) for _ in range(int(rng.integers(11000, 14000)))]
         text = rng.integers(96, 97 + span + 1, size=int(rng.integers(50000, 400000))).astype(np.uint8)
         return kws, text, 1, ({"ACM_GPU_GRAM": "0"} if kind == "sticky" else {})
+    if kind == "gramsmall":         # the 4-gram kernel forced onto small dictionaries (few 4-grams set, lmax down to 4)
+        lo = int(rng.integers(0, 220)); span = int(rng.integers(1, 29))
+        top = int(rng.integers(5, 12))
+        kws = [rng.integers(lo, lo + span, size=rng.integers(4, top)).astype(np.uint8) for _ in range(int(rng.integers(1, 1500)))]
+        text = rng.integers(max(lo - 1, 0), min(lo + span + 1, 256), size=int(rng.integers(1, 200000))).astype(np.uint8)
+        return kws, text, 1, {"ACM_GPU_GRAM": "2"}
     if kind == "short":             # > 32768 states but keywords shorter than 4: not eligible for the 4-gram kernel
         kws = [rng.integers(97, 123, size=rng.integers(1, 12)).astype(np.uint8) for _ in range(int(rng.integers(10000, 12000)))]
         text = rng.integers(97, 123, size=int(rng.integers(50000, 300000))).astype(np.uint8)
@@ -602,7 +608,7 @@ def _random_case(rng, kind):
     return kws, text, sym, ({"ACM_GPU_SPARSE": "walk"} if kind.startswith("walk") else {})
 
 
-@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "gram", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
+@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "gram", "gramsmall", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
                                        for s in range(int(os.environ.get("ACM_SOAK_SEEDS", "3")))])   # ACM_SOAK_SEEDS=14: a soak run
 def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed):
     """Random dictionaries and texts through every kernel family; whole scans, count-only scans and
@@ -621,7 +627,7 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
             text[at:at + w.size] = w
     m, o = build_pair(kws, sym)
     plan = m.plan(0)
-    expect = {"dense": 1, "gram": 5, "sticky": 1, "short": 1, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
+    expect = {"dense": 1, "gram": 5, "gramsmall": 5, "sticky": 1, "short": 1, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
     if kind in ("gram", "sticky", "short"):
         assert plan.info.dense_rows > 32768, "the generator is meant to give more states than the LDS scheme takes"
     assert plan.info.kernel == expect, (kind, plan.info.kernel)
