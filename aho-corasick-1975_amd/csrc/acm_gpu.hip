@@ -185,6 +185,7 @@ struct ACMPlan {
   StartsMirror *mir = nullptr; /* starts plans: what acm_gpu_plan_update edits */
   GramK GK{};
   bool gram = false; /* 4-gram sieve kernel instead of the sticky dense walk */
+  bool gram_shorts = false;
   uint32_t gram_lds_bytes = 0;
   uint32_t class_sym_bytes = 0; /* comparator-class plans: the symbol size they were made for */
   bool sparse = false, sparse_lut_lds = false, starts_lut_lds = false;
@@ -298,6 +299,15 @@ starts_fn (bool lut_lds, bool count_only) {
                       : reinterpret_cast<const void *> (&scan_starts_kernel<SYM, true, false>);
   return count_only ? reinterpret_cast<const void *> (&scan_starts_kernel<SYM, false, true>)
                     : reinterpret_cast<const void *> (&scan_starts_kernel<SYM, false, false>);
+}
+
+const void *
+gram_kernel_ptr (bool count_only, bool shorts) {
+  if (shorts)
+    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, true>)
+                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, true>);
+  return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, false>)
+                    : reinterpret_cast<const void *> (&scan_gram_kernel<false, false>);
 }
 
 const void *
@@ -423,13 +433,18 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const char *gram_env = getenv ("ACM_GPU_GRAM"); /* 0: never; 2: also for dictionaries the LDS scheme takes (experiments) */
   const int gram_mode = gram_env ? atoi (gram_env) : 1;
   bool gram = dense && (entry_bytes == 4 || gram_mode == 2) && gram_mode != 0 && fi.width <= 30 && fi.width == fi.alpha_span + 1 &&
-              fi.lmax >= 4 && n < 0x40000000u && fi.lmax + 1 >= 5;
+              fi.lmax >= 4 && n < 0x40000000u;
+  bool gram_shorts = false; /* keywords of 1-3 symbols: the kernel's nibble table and third queue */
   for (uint32_t k = 0; k < fi.n_keywords && gram; k++)
-    gram = fv.depth[fv.kw_state[k]] >= 4;
+    gram_shorts |= fv.depth[fv.kw_state[k]] < 4;
   const uint32_t gW = fi.width;
   const uint32_t gW4 = gram ? gW * gW * gW * gW : 0;
   const uint32_t g4words = (gW4 + 31) / 32;
-  const size_t o_g4bits = blob_reserve (cur, gram ? (size_t)g4words * 4 + 16 : 0);
+  const uint32_t gW3 = gram ? gW * gW * gW : 0;
+  const uint32_t g3_off = (g4words * 4 + 15) & ~15u;                 /* nibble table right after the 4-gram bits */
+  const uint32_t g3_bytes = gram_shorts ? ((gW3 + 1) / 2 + 15) & ~15u : 0;
+  const size_t o_g4bits = blob_reserve (cur, gram ? (size_t)g3_off + g3_bytes + 16 : 0);
+  const size_t o_g3rec = blob_reserve (cur, gram_shorts ? (size_t)gW3 * 16 : 0);
   const size_t o_g4rec = blob_reserve (cur, gram ? (size_t)gW4 * 8 : 0);
   const size_t o_grec = blob_reserve (cur, gram ? (size_t)n * 32 : 0);
   const size_t o_gedge = blob_reserve (cur, gram ? (size_t)fi.n_edges * 8 : 0);
@@ -586,6 +601,23 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       g4[2 * (size_t)idx] = mask;
       g4[2 * (size_t)idx + 1] = st;
     }
+    if (gram_shorts) {
+      /* a keyword of d < 4 symbols with path p covers the 3-gram indices [p * W^(3-d), (p+1) * W^(3-d)) */
+      unsigned char *nib = &host[o_g4bits + g3_off];
+      uint32_t *g3 = reinterpret_cast<uint32_t *> (&host[o_g3rec]);
+      for (uint32_t st = 1; st < fv.depth_start[4]; st++) {
+        if (fv.term_kw[st] == NONE)
+          continue;
+        const uint32_t d = fv.depth[st];
+        uint32_t width = 1;
+        for (uint32_t k = d; k < 3; k++)
+          width *= gW;
+        for (uint32_t i3 = path[st] * width; i3 < (path[st] + 1) * width; i3++) {
+          nib[i3 >> 1] |= (unsigned char)((1u << (d - 1)) << ((i3 & 1) * 4));
+          g3[4 * (size_t)i3 + (d - 1)] = st;
+        }
+      }
+    }
   }
   if (dense) {
     int rc = acm_flat_dense_rows (flat, n, entry_bytes, &host[o_dense]);
@@ -654,8 +686,8 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   p->d_dstart = u32p (o_dstart);
   if (gram) {
     const uint32_t lds_total = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
-    const uint32_t gq = (SPARSE_THREADS / WAVE) * (2 * QCAP + HITS_STRIDE) * 8;
-    const uint32_t bits_bytes = (g4words * 4 + 15) & ~15u;
+    const uint32_t gq = (SPARSE_THREADS / WAVE) * ((gram_shorts ? 3 : 2) * QCAP + HITS_STRIDE) * 8;
+    const uint32_t bits_bytes = g3_off + g3_bytes;
     if ((uint64_t)bits_bytes + gq + WALK_CTX_BYTES <= lds_total) {
       p->gram = true;
       p->GK.g4rec = reinterpret_cast<const uint2 *> (b + o_g4rec);
@@ -665,6 +697,10 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       p->GK.g4gid = u32p (o_g4gid);
       p->GK.d4_begin = fv.depth_start[4];
       p->GK.g4words = g4words;
+      p->GK.g3rec = reinterpret_cast<const uint4 *> (b + o_g3rec);
+      p->GK.g3_off = g3_off;
+      p->GK.g3_bytes = g3_bytes;
+      p->gram_shorts = gram_shorts;
       p->GK.W = gW;
       p->GK.lo = fi.alpha_lo;
       p->GK.span = fi.alpha_span;
@@ -770,10 +806,9 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     }
   }
   if (p->gram) {
-    HIP_TRY (hipFuncSetAttribute (reinterpret_cast<const void *> (&scan_gram_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->gram_lds_bytes));
-    HIP_TRY (hipFuncSetAttribute (reinterpret_cast<const void *> (&scan_gram_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->gram_lds_bytes));
+    for (int co = 0; co < 2; co++)
+      HIP_TRY (hipFuncSetAttribute (gram_kernel_ptr (co != 0, p->gram_shorts), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)p->gram_lds_bytes));
   }
   if (dense) {
     for (int co = 0; co < 2; co++)
@@ -1068,7 +1103,7 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
   void *items = COUNT_ONLY ? nullptr : p->d_items;
   uint32_t *fill = COUNT_ONLY ? nullptr : p->d_fill;
   void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
-  HIP_TRY (hipLaunchKernel (reinterpret_cast<const void *> (&scan_gram_kernel<COUNT_ONLY>), dim3 (grid), dim3 (SPARSE_THREADS), args,
+  HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts), dim3 (grid), dim3 (SPARSE_THREADS), args,
                             p->gram_lds_bytes, st));
   if (!COUNT_ONLY)
     launch_expand_hits (p, E, grid * wpb, st);

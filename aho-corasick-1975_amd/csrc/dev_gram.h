@@ -5,8 +5,8 @@
 /* ------------------------------------------------------------------ 4-gram sieve kernel (byte alphabets, big dictionaries)
  * Dictionaries whose automaton does not fit the LDS scheme of the dense kernel (more than 32,768
  * states: config 3 has 508,339) make every step of a carried-state walk a dependent gather into
- * tens of megabytes of rows (99 GB/s).  When every keyword has at least 4 symbols and the
- * alphabet is small (width W = span + 1 <= 30), the start-parallel idea works for bytes too:
+ * tens of megabytes of rows (99 GB/s).  When the alphabet is small (width W = span + 1 <= 30)
+ * the start-parallel idea works for bytes too.  Keywords of 4 symbols or more:
  *   1. LDS holds one bit per possible 4-gram over the W classes (W^4 bits: 66 KB for a-z): "some
  *      keyword starts with it".  Every position is tested with one ds_read_b32 on a rolling
  *      4-gram index (config 3: 19.6% pass);
@@ -17,6 +17,9 @@
  *      reported on the spot, or a 5-symbol prefix of a keyword does);
  *   3. the latter (0.75%) go to walk_starts (shared with the start-parallel kernel) at the
  *      depth-4 state; the trie records below depth 4 are laid out depth-first.
+ * Keywords of 1-3 symbols (template SHORTS, only if the dictionary has any): a nibble per 3-gram
+ * in LDS (bit d-1: the first d symbols are a keyword) looked up on a second rolling index, a third
+ * queue, and per 3-gram the states of its three prefixes in HBM for the records.
  * Text is read as in the start-parallel kernel (1 KiB groups, 16 bytes per lane, four groups in
  * flight). */
 struct GramK {
@@ -27,12 +30,16 @@ struct GramK {
   const uint32_t *g4gid;  /* [states of depth 4] record index of each depth-4 state */
   uint32_t d4_begin;      /* breadth-first id of the first depth-4 state */
   uint32_t g4words;
+  /* dictionaries with keywords of 1-3 symbols: per 3-gram a nibble in LDS (bit d-1: the first d
+   * symbols are a keyword) and a record {state of the 1-, 2-, 3-symbol prefix, -} in HBM */
+  const uint4 *g3rec;
+  uint32_t g3_off, g3_bytes; /* nibble table in LDS, right after the 4-gram bits; 0 bytes: no short keywords */
   uint32_t W, lo, span, W4; /* class = min (byte - lo, span); W = span + 1 */
   uint32_t R;             /* groups per tile */
   uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
 };
 
-template <bool COUNT_ONLY>
+template <bool COUNT_ONLY, bool SHORTS>
 __global__ __launch_bounds__ (SPARSE_THREADS) void
 scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
                   uint32_t *fill) {
@@ -42,10 +49,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   {
     uint4 *dst = reinterpret_cast<uint4 *> (smem);
     const uint4 *src = reinterpret_cast<const uint4 *> (K.g4bits);
-    for (uint32_t i = threadIdx.x; i < (K.g4words + 3) / 4; i += blockDim.x)
-      dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < (K.g3_off + K.g3_bytes + 15) / 16; i += blockDim.x)
+      dst[i] = src[i]; /* 4-gram bits, then (g3_off) the nibbles of the short keywords */
   }
-  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (2 * QCAP + HITS_STRIDE) * 8);
+  constexpr uint32_t NQ = SHORTS ? 3 : 2; /* queues per wave */
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (NQ * QCAP + HITS_STRIDE) * 8);
   StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4); /* see scan_starts_kernel */
   EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
   if (threadIdx.x == 0) {
@@ -64,7 +72,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   const uint32_t wib = uniform (threadIdx.x / WAVE);
   uint2 *q1 = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
   uint2 *q2 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * QCAP;
-  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + 2 * WAVES * QCAP + wib * HITS_STRIDE + 2;
+  uint2 *q3 = reinterpret_cast<uint2 *> (smem + K.queue_off) + 2 * WAVES * QCAP + wib * QCAP; /* SHORTS only */
+  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + NQ * WAVES * QCAP + wib * HITS_STRIDE + 2;
   const uint32_t wave_id = blockIdx.x * WAVES + wib;
   hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
   const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
@@ -73,7 +82,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
    * handed to its waves through the LDS counter */
   const TileShare share (A);
   const uint32_t last_blk = (A.n - 1) / 16;
-  uint32_t qn1 = 0, qn2 = 0;
+  uint32_t qn1 = 0, qn2 = 0, qn3 = 0;
   unsigned long long counted = 0;
   /* batches of the first queue whose records are in flight: a pipeline of GRAM_DEPTH batches
    * (the gather of a batch has the time it takes the scan to fill that many more before it is
@@ -139,6 +148,24 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     pend_n[GRAM_DEPTH - 1] = n_items;
   };
 
+  /* the newest n items of the short-keyword queue: item = (position, 3-gram index | nibble << 20);
+   * the keywords of 1, 2, 3 symbols that start there end at position, +1, +2 */
+  auto short_batch = [&] (uint32_t n_items) {
+    qn3 -= n_items;
+    const uint2 it = lane < n_items ? q3[qn3 + lane] : make_uint2 (0, 0);
+    const uint32_t nib = it.y >> 20;
+    uint4 rec = make_uint4 (0, 0, 0, 0);
+    if (!COUNT_ONLY)
+      rec = K.g3rec[it.y & 0xFFFFFu];
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++) {
+      const bool hit = ((nib >> d) & 1u) && it.x + d >= E.emit_from;
+      emit_terminals<COUNT_ONLY> (E, hit, it.x + d, d == 0 ? rec.x : (d == 1 ? rec.y : rec.z), lane, hits, counted);
+      if (!COUNT_ONLY)
+        counted = uniform ((uint32_t)counted);
+    }
+  };
+
   /* one group: cur = this lane's 16 bytes, next_x = the first 4 bytes of every lane of the next group */
   auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t g) {
     uint32_t after = __shfl_down (cur.x, 1, WAVE);
@@ -161,17 +188,38 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           c[j] = K.span;
     }
     uint32_t idx = ((c[0] * K.W + c[1]) * K.W + c[2]) * K.W + c[3];
+    uint32_t idx3 = (c[0] * K.W + c[1]) * K.W + c[2];
+    const uint32_t W3 = SHORTS ? K.W * K.W * K.W : 0u;
     /* eight positions at a time: all their table words are asked for before any is looked at
      * (slot by slot, every ds_read waited behind the queue's ds_write of the slot before it,
      * which the compiler must assume to alias: 16 LDS round trips in a row per group) */
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      uint32_t ix[8], word[8];
+      uint32_t ix[8], word[8], ix3[SHORTS ? 8 : 1], nibs[SHORTS ? 8 : 1];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         ix[j] = idx;
         word[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
         idx = idx * K.W + c[8 * h + j + 4] - c[8 * h + j] * K.W4;
+        if (SHORTS) {
+          ix3[j] = idx3;
+          nibs[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) unsigned char *> (K.g3_off + (idx3 >> 1));
+          idx3 = idx3 * K.W + c[8 * h + j + 3] - c[8 * h + j] * W3;
+        }
+      }
+      if (SHORTS) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t nib = (nibs[j] >> ((ix3[j] & 1u) * 4u)) & 7u;
+          const uint64_t m = __ballot (nib != 0);
+          if (m) {
+            if (nib)
+              q3[qn3 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos0 + 8 * h + j, ix3[j] | (nib << 20));
+            qn3 = uniform (qn3 + (uint32_t)__popcll (m));
+            if (qn3 >= WAVE)
+              short_batch (WAVE);
+          }
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
@@ -217,6 +265,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     consume_oldest ();
   while (qn2)
     walk_batch (qn2 < WAVE ? qn2 : WAVE);
+  if (SHORTS && qn3)
+    short_batch (qn3);
   if (COUNT_ONLY) {
     const uint32_t incl = wave_incl_scan ((uint32_t)counted);
     const uint32_t total = __shfl (incl, WAVE - 1, WAVE);

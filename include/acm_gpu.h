@@ -143,7 +143,7 @@ typedef struct {
                             (root table by symbol value, every position verified independently), or
                             3 = sparse automaton walk when the environment says ACM_GPU_SPARSE=walk;
                             5 = 4-gram sieve kernel: byte alphabets of at most 29 symbols, more than 32,768
-                            states, every keyword at least 4 symbols long (ACM_GPU_GRAM=0: kernel 1 instead) */
+                            states (ACM_GPU_GRAM=0: kernel 1 instead) */
   uint32_t entry_bytes;  /* dense entries: 2 or 4 */
   uint32_t width;        /* dense row width */
   uint32_t dense_rows;   /* rows resident in HBM */

@@ -593,10 +593,12 @@ def _random_case(rng, kind):
     if kind == "gramsmall":         # the 4-gram kernel forced onto small dictionaries (few 4-grams set, lmax down to 4)
         lo = int(rng.integers(0, 220)); span = int(rng.integers(1, 29))
         top = int(rng.integers(5, 12))
-        kws = [rng.integers(lo, lo + span, size=rng.integers(4, top)).astype(np.uint8) for _ in range(int(rng.integers(1, 1500)))]
+        shortest = 4 if rng.integers(0, 2) else 1      # with or without keywords of 1-3 symbols
+        kws = [rng.integers(lo, lo + span, size=rng.integers(shortest, top)).astype(np.uint8) for _ in range(int(rng.integers(1, 1500)))]
+        kws.append(rng.integers(lo, lo + span, size=top).astype(np.uint8))      # at least one keyword of 4 symbols or more
         text = rng.integers(max(lo - 1, 0), min(lo + span + 1, 256), size=int(rng.integers(1, 200000))).astype(np.uint8)
         return kws, text, 1, {"ACM_GPU_GRAM": "2"}
-    if kind == "short":             # > 32768 states but keywords shorter than 4: not eligible for the 4-gram kernel
+    if kind == "short":             # > 32768 states and keywords of 1-3 symbols too: the 4-gram kernel with its short-keyword path
         kws = [rng.integers(97, 123, size=rng.integers(1, 12)).astype(np.uint8) for _ in range(int(rng.integers(10000, 12000)))]
         text = rng.integers(97, 123, size=int(rng.integers(50000, 300000))).astype(np.uint8)
         return kws, text, 1, {}
@@ -627,7 +629,7 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
             text[at:at + w.size] = w
     m, o = build_pair(kws, sym)
     plan = m.plan(0)
-    expect = {"dense": 1, "gram": 5, "gramsmall": 5, "sticky": 1, "short": 1, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
+    expect = {"dense": 1, "gram": 5, "gramsmall": 5, "sticky": 1, "short": 5, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
     if kind in ("gram", "sticky", "short"):
         assert plan.info.dense_rows > 32768, "the generator is meant to give more states than the LDS scheme takes"
     assert plan.info.kernel == expect, (kind, plan.info.kernel)
