@@ -185,7 +185,7 @@ struct ACMPlan {
   StartsMirror *mir = nullptr; /* starts plans: what acm_gpu_plan_update edits */
   GramK GK{};
   bool gram = false; /* 4-gram sieve kernel instead of the sticky dense walk */
-  bool gram_shorts = false;
+  bool gram_shorts = false, gram_wide = false;
   uint32_t gram_lds_bytes = 0;
   uint32_t class_sym_bytes = 0; /* comparator-class plans: the symbol size they were made for */
   bool sparse = false, sparse_lut_lds = false, starts_lut_lds = false;
@@ -302,12 +302,15 @@ starts_fn (bool lut_lds, bool count_only) {
 }
 
 const void *
-gram_kernel_ptr (bool count_only, bool shorts) {
+gram_kernel_ptr (bool count_only, bool shorts, bool wide) {
+  if (wide)
+    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, false, true>)
+                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, true>);
   if (shorts)
-    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, true>)
-                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, true>);
-  return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, false>)
-                    : reinterpret_cast<const void *> (&scan_gram_kernel<false, false>);
+    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, true, false>)
+                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, true, false>);
+  return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, false, false>)
+                    : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, false>);
 }
 
 const void *
@@ -432,15 +435,25 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
    * scheme, every keyword at least 4 symbols long */
   const char *gram_env = getenv ("ACM_GPU_GRAM"); /* 0: never; 2: also for dictionaries the LDS scheme takes (experiments) */
   const int gram_mode = gram_env ? atoi (gram_env) : 1;
-  bool gram = dense && (entry_bytes == 4 || gram_mode == 2) && gram_mode != 0 && fi.width <= 30 && fi.width == fi.alpha_span + 1 &&
-              fi.lmax >= 4 && n < 0x40000000u;
+  const bool gram_big = dense && (entry_bytes == 4 || gram_mode == 2) && gram_mode != 0 && fi.lmax >= 4 && n < 0x40000000u;
+  const bool gram_narrow = fi.width <= 30 && fi.width == fi.alpha_span + 1;
   bool gram_shorts = false; /* keywords of 1-3 symbols: the kernel's nibble table and third queue */
-  for (uint32_t k = 0; k < fi.n_keywords && gram; k++)
+  for (uint32_t k = 0; k < fi.n_keywords && gram_big; k++)
     gram_shorts |= fv.depth[fv.kw_state[k]] < 4;
+  /* wide alphabets: hashed 4-byte windows instead of the exact base-W index; no short keywords */
+  const bool gram_wide = gram_big && !gram_narrow && !gram_shorts;
+  bool gram = gram_big && (gram_narrow || gram_wide);
+  if (!gram || gram_wide)
+    gram_shorts = false;
   const uint32_t gW = fi.width;
-  const uint32_t gW4 = gram ? gW * gW * gW * gW : 0;
-  const uint32_t g4words = (gW4 + 31) / 32;
-  const uint32_t gW3 = gram ? gW * gW * gW : 0;
+  const uint32_t bloom_log2 = 19; /* wide: 64 KB of Bloom bits */
+  const uint32_t n_depth4 = gram ? fv.depth_start[5] - fv.depth_start[4] : 0;
+  uint32_t wtab_log2 = 4;
+  while (gram_wide && (1u << wtab_log2) < 2 * n_depth4 + 2)
+    wtab_log2++;
+  const uint32_t gW4 = !gram ? 0 : (gram_wide ? 1u << wtab_log2 : gW * gW * gW * gW); /* 8-byte records of the second stage */
+  const uint32_t g4words = gram ? (gram_wide ? (1u << bloom_log2) / 32 : (gW4 + 31) / 32) : 0;
+  const uint32_t gW3 = gram && !gram_wide ? gW * gW * gW : 0;
   const uint32_t g3_off = (g4words * 4 + 15) & ~15u;                 /* nibble table right after the 4-gram bits */
   const uint32_t g3_bytes = gram_shorts ? ((gW3 + 1) / 2 + 15) & ~15u : 0;
   const size_t o_g4bits = blob_reserve (cur, gram ? (size_t)g3_off + g3_bytes + 16 : 0);
@@ -591,8 +604,19 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     std::vector<uint32_t> path (fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1], 0);
     for (uint32_t st = 0; st < fv.depth_start[4]; st++)
       for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
-        path[fv.edge_next[e]] = path[st] * gW + (fv.edge_sym[e] - fi.alpha_lo);
-    for (uint32_t st = fv.depth_start[4]; st < fv.depth_start[5]; st++) {
+        path[fv.edge_next[e]] = gram_wide ? path[st] | (fv.edge_sym[e] << (8 * fv.depth[st])) /* the 4 bytes as the text holds them */
+                                          : path[st] * gW + (fv.edge_sym[e] - fi.alpha_lo);
+    for (uint32_t st = fv.depth_start[4]; gram_wide && st < fv.depth_start[5]; st++) {
+      const uint32_t win = path[st];
+      const uint32_t hb = (win * WIDE_H1) >> (32 - bloom_log2);
+      bits[hb >> 5] |= 1u << (hb & 31);
+      uint32_t slot = (win * WIDE_H2) >> (32 - wtab_log2);
+      while (g4[2 * (size_t)slot + 1])
+        slot = (slot + 1) & ((1u << wtab_log2) - 1);
+      g4[2 * (size_t)slot] = win;
+      g4[2 * (size_t)slot + 1] = st | (fv.term_kw[st] != NONE ? WT_TERM : 0u) | (fv.row_ptr[st + 1] > fv.row_ptr[st] ? WT_KIDS : 0u);
+    }
+    for (uint32_t st = fv.depth_start[4]; !gram_wide && st < fv.depth_start[5]; st++) {
       const uint32_t idx = path[st];
       uint32_t mask = fv.term_kw[st] != NONE ? 0x80000000u : 0u;
       for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
@@ -700,7 +724,11 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       p->GK.g3rec = reinterpret_cast<const uint4 *> (b + o_g3rec);
       p->GK.g3_off = g3_off;
       p->GK.g3_bytes = g3_bytes;
+      p->GK.wtab = reinterpret_cast<const uint2 *> (b + o_g4rec);
+      p->GK.bloom_log2 = bloom_log2;
+      p->GK.wtab_log2 = wtab_log2;
       p->gram_shorts = gram_shorts;
+      p->gram_wide = gram_wide;
       p->GK.W = gW;
       p->GK.lo = fi.alpha_lo;
       p->GK.span = fi.alpha_span;
@@ -807,7 +835,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   }
   if (p->gram) {
     for (int co = 0; co < 2; co++)
-      HIP_TRY (hipFuncSetAttribute (gram_kernel_ptr (co != 0, p->gram_shorts), hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIP_TRY (hipFuncSetAttribute (gram_kernel_ptr (co != 0, p->gram_shorts, p->gram_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)p->gram_lds_bytes));
   }
   if (dense) {
@@ -1103,7 +1131,7 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
   void *items = COUNT_ONLY ? nullptr : p->d_items;
   uint32_t *fill = COUNT_ONLY ? nullptr : p->d_fill;
   void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
-  HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts), dim3 (grid), dim3 (SPARSE_THREADS), args,
+  HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts, p->gram_wide), dim3 (grid), dim3 (SPARSE_THREADS), args,
                             p->gram_lds_bytes, st));
   if (!COUNT_ONLY)
     launch_expand_hits (p, E, grid * wpb, st);

@@ -20,6 +20,9 @@
  * Keywords of 1-3 symbols (template SHORTS, only if the dictionary has any): a nibble per 3-gram
  * in LDS (bit d-1: the first d symbols are a keyword) looked up on a second rolling index, a third
  * queue, and per 3-gram the states of its three prefixes in HBM for the records.
+ * Alphabets of more than 29 symbols (template WIDE; every keyword >= 4 symbols): the raw 4-byte
+ * window replaces the base-W index -- a multiplicative hash into Bloom bits in LDS for stage 1, an
+ * open-addressing table {window, depth-4 state | flags} in HBM for stage 2.
  * Text is read as in the start-parallel kernel (1 KiB groups, 16 bytes per lane, four groups in
  * flight). */
 struct GramK {
@@ -34,12 +37,20 @@ struct GramK {
    * symbols are a keyword) and a record {state of the 1-, 2-, 3-symbol prefix, -} in HBM */
   const uint4 *g3rec;
   uint32_t g3_off, g3_bytes; /* nibble table in LDS, right after the 4-gram bits; 0 bytes: no short keywords */
+  /* wide alphabets (template WIDE): g4bits is a Bloom filter of 2^bloom_log2 bits on the hashed
+   * 4-byte window, wtab an open-addressing table {window, depth-4 state | has children << 30 |
+   * terminal << 31} of 2^wtab_log2 slots (state 0: empty slot) */
+  const uint2 *wtab;
+  uint32_t bloom_log2, wtab_log2;
   uint32_t W, lo, span, W4; /* class = min (byte - lo, span); W = span + 1 */
   uint32_t R;             /* groups per tile */
   uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
 };
 
-template <bool COUNT_ONLY, bool SHORTS>
+constexpr uint32_t WIDE_H1 = 0x9E3779B1u, WIDE_H2 = 0x85EBCA6Bu; /* multiplicative hashes: Bloom bits, table slots */
+constexpr uint32_t WT_TERM = 0x80000000u, WT_KIDS = 0x40000000u;
+
+template <bool COUNT_ONLY, bool SHORTS, bool WIDE>
 __global__ __launch_bounds__ (SPARSE_THREADS) void
 scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
                   uint32_t *fill) {
@@ -114,14 +125,27 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   auto consume_oldest = [&] () {
     if (pend_n[0]) {
       const uint32_t c4 = pend_item[0].y >> 20;
-      const bool valid = lane < pend_n[0];
+      bool valid = lane < pend_n[0];
+      if (WIDE) {
+        /* the slot that came back is the first of the probe sequence: a hit, an empty slot (the
+         * Bloom bit was a false positive), or somebody else's window -- then probe on (rare) */
+        uint2 e = pend_rec[0];
+        uint32_t slot = (pend_item[0].y * WIDE_H2) >> (32 - K.wtab_log2);
+        while (valid && (e.y & ST_STATE) != 0 && e.x != pend_item[0].y) {
+          slot = (slot + 1) & ((1u << K.wtab_log2) - 1);
+          e = K.wtab[slot];
+        }
+        valid = valid && (e.y & ST_STATE) != 0;
+        /* same shape as the exact table's record: terminal bit 31, "goes on" as bit 0 of the mask */
+        pend_rec[0] = make_uint2 ((e.y & WT_TERM) | ((e.y & WT_KIDS) ? 1u : 0u), e.y & ST_STATE);
+      }
       /* a keyword of length 4 ends here: reported at once, its record needs nothing but the
        * state id (the trie records of the 508,339 states are 16 MB of HBM: not worth a visit) */
       const bool term = valid && (pend_rec[0].x >> 31) && pend_item[0].x + 3 >= E.emit_from;
       emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, pend_rec[0].y, lane, hits, counted);
       if (!COUNT_ONLY)
         counted = uniform ((uint32_t)counted);
-      const bool pass = valid && ((pend_rec[0].x >> c4) & 1u);
+      const bool pass = valid && ((pend_rec[0].x >> (WIDE ? 0u : c4)) & 1u);
       const uint64_t m = __ballot (pass);
       if (m) {
         if (pass)
@@ -144,7 +168,10 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   auto issue_batch = [&] (uint32_t n_items) {
     qn1 -= n_items;
     pend_item[GRAM_DEPTH - 1] = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
-    pend_rec[GRAM_DEPTH - 1] = K.g4rec[pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu];
+    if (WIDE)
+      pend_rec[GRAM_DEPTH - 1] = K.wtab[(pend_item[GRAM_DEPTH - 1].y * WIDE_H2) >> (32 - K.wtab_log2)];
+    else
+      pend_rec[GRAM_DEPTH - 1] = K.g4rec[pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu];
     pend_n[GRAM_DEPTH - 1] = n_items;
   };
 
@@ -174,6 +201,38 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       after = after_group;
     const uint32_t pos0 = g * GROUP + lane * 16;
     const uint32_t w[5] = { cur.x, cur.y, cur.z, cur.w, after };
+    if constexpr (WIDE) {
+      /* the 4-byte window at every position (one v_alignbit each), hashed into the Bloom bits;
+       * windows that reach past the end of the segment are no starts (last groups only) */
+      const bool tail = pos0 + 20 > A.n;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        uint32_t win[8], word[8], hb[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int jj = 8 * h + j;
+          win[j] = jj % 4 ? __builtin_amdgcn_alignbit (w[jj / 4 + 1], w[jj / 4], 8 * (jj % 4)) : w[jj / 4];
+          hb[j] = (win[j] * WIDE_H1) >> (32 - K.bloom_log2);
+          word[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((hb[j] >> 5) * 4u);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t p = pos0 + 8 * h + j;
+          const bool push = ((word[j] >> (hb[j] & 31u)) & 1u) && (!tail || p + 3 < A.n);
+          const uint64_t m = __ballot (push);
+          if (m) {
+            if (push)
+              q1[qn1 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (p, win[j]);
+            qn1 = uniform (qn1 + (uint32_t)__popcll (m));
+            if (qn1 >= WAVE) {
+              consume_oldest ();
+              issue_batch (WAVE);
+            }
+          }
+        }
+      }
+      return;
+    }
     uint32_t c[20];
 #pragma unroll
     for (int j = 0; j < 20; j++) {
