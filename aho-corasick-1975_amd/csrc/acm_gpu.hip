@@ -303,6 +303,9 @@ starts_fn (bool lut_lds, bool count_only) {
 
 const void *
 gram_kernel_ptr (bool count_only, bool shorts, bool wide) {
+  if (wide && shorts)
+    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, true, true>)
+                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, true, true>);
   if (wide)
     return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, false, true>)
                       : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, true>);
@@ -440,10 +443,10 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   bool gram_shorts = false; /* keywords of 1-3 symbols: the kernel's nibble table and third queue */
   for (uint32_t k = 0; k < fi.n_keywords && gram_big; k++)
     gram_shorts |= fv.depth[fv.kw_state[k]] < 4;
-  /* wide alphabets: hashed 4-byte windows instead of the exact base-W index; no short keywords */
-  const bool gram_wide = gram_big && !gram_narrow && !gram_shorts;
-  bool gram = gram_big && (gram_narrow || gram_wide);
-  if (!gram || gram_wide)
+  /* wide alphabets: hashed 4-byte windows instead of the exact base-W index */
+  const bool gram_wide = gram_big && !gram_narrow;
+  bool gram = gram_big;
+  if (!gram)
     gram_shorts = false;
   const uint32_t gW = fi.width;
   const uint32_t bloom_log2 = 19; /* wide: 64 KB of Bloom bits */
@@ -451,13 +454,23 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   uint32_t wtab_log2 = 4;
   while (gram_wide && (1u << wtab_log2) < 2 * n_depth4 + 2)
     wtab_log2++;
+  uint32_t n_short = 0, short_lens = 0; /* wide alphabets: keywords of 1-3 symbols */
+  for (uint32_t k = 0; k < fi.n_keywords && gram_wide && gram_shorts; k++)
+    if (fv.depth[fv.kw_state[k]] < 4) {
+      n_short++;
+      short_lens |= 1u << (fv.depth[fv.kw_state[k]] - 1);
+    }
+  uint32_t stab_log2 = 4;
+  while ((1u << stab_log2) < 2 * n_short + 2)
+    stab_log2++;
   const uint32_t gW4 = !gram ? 0 : (gram_wide ? 1u << wtab_log2 : gW * gW * gW * gW); /* 8-byte records of the second stage */
   const uint32_t g4words = gram ? (gram_wide ? (1u << bloom_log2) / 32 : (gW4 + 31) / 32) : 0;
   const uint32_t gW3 = gram && !gram_wide ? gW * gW * gW : 0;
   const uint32_t g3_off = (g4words * 4 + 15) & ~15u;                 /* nibble table right after the 4-gram bits */
-  const uint32_t g3_bytes = gram_shorts ? ((gW3 + 1) / 2 + 15) & ~15u : 0;
+  const uint32_t g3_bytes = gram_shorts && !gram_wide ? ((gW3 + 1) / 2 + 15) & ~15u : 0;
   const size_t o_g4bits = blob_reserve (cur, gram ? (size_t)g3_off + g3_bytes + 16 : 0);
-  const size_t o_g3rec = blob_reserve (cur, gram_shorts ? (size_t)gW3 * 16 : 0);
+  const size_t o_g3rec = blob_reserve (cur, gram_shorts && !gram_wide ? (size_t)gW3 * 16 : 0);
+  const size_t o_stab = blob_reserve (cur, gram_wide && gram_shorts ? ((size_t)8 << stab_log2) : 0);
   const size_t o_g4rec = blob_reserve (cur, gram ? (size_t)gW4 * 8 : 0);
   const size_t o_grec = blob_reserve (cur, gram ? (size_t)n * 32 : 0);
   const size_t o_gedge = blob_reserve (cur, gram ? (size_t)fi.n_edges * 8 : 0);
@@ -625,7 +638,22 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       g4[2 * (size_t)idx] = mask;
       g4[2 * (size_t)idx + 1] = st;
     }
-    if (gram_shorts) {
+    if (gram_shorts && gram_wide) {
+      uint32_t *stab = reinterpret_cast<uint32_t *> (&host[o_stab]);
+      for (uint32_t st = 1; st < fv.depth_start[4]; st++) {
+        if (fv.term_kw[st] == NONE)
+          continue;
+        const uint32_t key = path[st] | (fv.depth[st] << 24);
+        const uint32_t hb = (key * WIDE_H1) >> (32 - bloom_log2);
+        bits[hb >> 5] |= 1u << (hb & 31);
+        uint32_t slot = (key * WIDE_H2) >> (32 - stab_log2);
+        while (stab[2 * (size_t)slot + 1])
+          slot = (slot + 1) & ((1u << stab_log2) - 1);
+        stab[2 * (size_t)slot] = key;
+        stab[2 * (size_t)slot + 1] = st;
+      }
+    }
+    if (gram_shorts && !gram_wide) {
       /* a keyword of d < 4 symbols with path p covers the 3-gram indices [p * W^(3-d), (p+1) * W^(3-d)) */
       unsigned char *nib = &host[o_g4bits + g3_off];
       uint32_t *g3 = reinterpret_cast<uint32_t *> (&host[o_g3rec]);
@@ -727,6 +755,9 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       p->GK.wtab = reinterpret_cast<const uint2 *> (b + o_g4rec);
       p->GK.bloom_log2 = bloom_log2;
       p->GK.wtab_log2 = wtab_log2;
+      p->GK.stab = reinterpret_cast<const uint2 *> (b + o_stab);
+      p->GK.stab_log2 = stab_log2;
+      p->GK.short_lens = short_lens;
       p->gram_shorts = gram_shorts;
       p->gram_wide = gram_wide;
       p->GK.W = gW;

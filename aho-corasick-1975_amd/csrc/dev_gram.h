@@ -20,7 +20,7 @@
  * Keywords of 1-3 symbols (template SHORTS, only if the dictionary has any): a nibble per 3-gram
  * in LDS (bit d-1: the first d symbols are a keyword) looked up on a second rolling index, a third
  * queue, and per 3-gram the states of its three prefixes in HBM for the records.
- * Alphabets of more than 29 symbols (template WIDE; every keyword >= 4 symbols): the raw 4-byte
+ * Alphabets of more than 29 symbols (template WIDE): the raw 4-byte
  * window replaces the base-W index -- a multiplicative hash into Bloom bits in LDS for stage 1, an
  * open-addressing table {window, depth-4 state | flags} in HBM for stage 2.
  * Text is read as in the start-parallel kernel (1 KiB groups, 16 bytes per lane, four groups in
@@ -42,6 +42,10 @@ struct GramK {
    * terminal << 31} of 2^wtab_log2 slots (state 0: empty slot) */
   const uint2 *wtab;
   uint32_t bloom_log2, wtab_log2;
+  /* wide alphabets with keywords of 1-3 symbols: their windows, keyed (bytes | length << 24), share
+   * the Bloom bits and have their own table {key, state}; short_lens bit d-1: some keyword has d symbols */
+  const uint2 *stab;
+  uint32_t stab_log2, short_lens;
   uint32_t W, lo, span, W4; /* class = min (byte - lo, span); W = span + 1 */
   uint32_t R;             /* groups per tile */
   uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
@@ -180,6 +184,21 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   auto short_batch = [&] (uint32_t n_items) {
     qn3 -= n_items;
     const uint2 it = lane < n_items ? q3[qn3 + lane] : make_uint2 (0, 0);
+    if constexpr (WIDE) {
+      /* item = (position, bytes | length << 24): look the key up (the Bloom bit may have lied) */
+      bool valid = lane < n_items;
+      uint32_t slot = (it.y * WIDE_H2) >> (32 - K.stab_log2);
+      uint2 e = K.stab[slot];
+      while (valid && e.y != 0 && e.x != it.y) {
+        slot = (slot + 1) & ((1u << K.stab_log2) - 1);
+        e = K.stab[slot];
+      }
+      const uint32_t end = it.x + (it.y >> 24) - 1;
+      emit_terminals<COUNT_ONLY> (E, valid && e.y != 0 && end >= E.emit_from, end, e.y, lane, hits, counted);
+      if (!COUNT_ONLY)
+        counted = uniform ((uint32_t)counted);
+      return;
+    }
     const uint32_t nib = it.y >> 20;
     uint4 rec = make_uint4 (0, 0, 0, 0);
     if (!COUNT_ONLY)
@@ -227,6 +246,35 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
             if (qn1 >= WAVE) {
               consume_oldest ();
               issue_batch (WAVE);
+            }
+          }
+        }
+        if (SHORTS) {
+          /* keywords of d = 1, 2, 3 symbols (only the lengths the dictionary has): the first d
+           * bytes of the window, tagged with d, through the same Bloom bits */
+#pragma unroll
+          for (uint32_t d = 1; d <= 3; d++) {
+            if (!((K.short_lens >> (d - 1)) & 1u))
+              continue;
+            uint32_t key[8], sw[8], sh[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              key[j] = (win[j] & ((1u << (8 * d)) - 1u)) | (d << 24);
+              sh[j] = (key[j] * WIDE_H1) >> (32 - K.bloom_log2);
+              sw[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((sh[j] >> 5) * 4u);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const uint32_t p = pos0 + 8 * h + j;
+              const bool push = ((sw[j] >> (sh[j] & 31u)) & 1u) && (!tail || p + d - 1 < A.n);
+              const uint64_t m = __ballot (push);
+              if (m) {
+                if (push)
+                  q3[qn3 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (p, key[j]);
+                qn3 = uniform (qn3 + (uint32_t)__popcll (m));
+                if (qn3 >= WAVE)
+                  short_batch (WAVE);
+              }
             }
           }
         }

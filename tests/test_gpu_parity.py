@@ -598,11 +598,11 @@ def _random_case(rng, kind):
         kws.append(rng.integers(lo, lo + span, size=top).astype(np.uint8))      # at least one keyword of 4 symbols or more
         text = rng.integers(max(lo - 1, 0), min(lo + span + 1, 256), size=int(rng.integers(1, 200000))).astype(np.uint8)
         return kws, text, 1, {"ACM_GPU_GRAM": "2"}
-    if kind == "wide":              # more than 29 symbols in use, > 32768 states, keywords >= 4: hashed 4-byte windows
+    if kind in ("wide", "wideshort"):   # more than 29 symbols in use, > 32768 states: hashed 4-byte windows (and shorter ones)
         lo = int(rng.integers(0, 120)); span = int(rng.integers(31, 136))
         if rng.integers(0, 3) == 0:
             lo, span = 0, 256           # every byte value in use: dense rows of width 256
-        kws = [rng.integers(lo, lo + span, size=rng.integers(4, 11)).astype(np.uint8) for _ in range(int(rng.integers(9000, 12000)))]
+        kws = [rng.integers(lo, lo + span, size=rng.integers(4 if kind == "wide" else 1, 11)).astype(np.uint8) for _ in range(int(rng.integers(9000, 12000)))]
         text = rng.integers(lo, lo + span, size=int(rng.integers(50000, 400000))).astype(np.uint8)
         # dense 4-gram hits: re-use keyword heads so that the table, not only the Bloom bits, is exercised
         for _ in range(3000):
@@ -623,7 +623,7 @@ def _random_case(rng, kind):
     return kws, text, sym, ({"ACM_GPU_SPARSE": "walk"} if kind.startswith("walk") else {})
 
 
-@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "gram", "gramsmall", "wide", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
+@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "gram", "gramsmall", "wide", "wideshort", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
                                        for s in range(int(os.environ.get("ACM_SOAK_SEEDS", "3")))])   # ACM_SOAK_SEEDS=14: a soak run
 def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed):
     """Random dictionaries and texts through every kernel family; whole scans, count-only scans and
@@ -642,8 +642,8 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
             text[at:at + w.size] = w
     m, o = build_pair(kws, sym)
     plan = m.plan(0)
-    expect = {"dense": 1, "gram": 5, "gramsmall": 5, "wide": 5, "sticky": 1, "short": 5, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
-    if kind in ("gram", "wide", "sticky", "short"):
+    expect = {"dense": 1, "gram": 5, "gramsmall": 5, "wide": 5, "wideshort": 5, "sticky": 1, "short": 5, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
+    if kind in ("gram", "wide", "wideshort", "sticky", "short"):
         assert plan.info.dense_rows > 32768, "the generator is meant to give more states than the LDS scheme takes"
     assert plan.info.kernel == expect, (kind, plan.info.kernel)
     want = o.scan(text)
