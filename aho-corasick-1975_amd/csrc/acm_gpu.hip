@@ -328,6 +328,198 @@ drop_cached_plan (void *p) {
 
 } // namespace
 
+namespace {
+/* ---- table builders of acm_gpu_plan_create_flat (host images of the device tables) */
+
+/* sparse automaton walk (dev_sparse.h): state records, (symbol, next | out flag) edges, root table */
+void
+fill_sparse_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, uint32_t lut_size, uint32_t *rec, uint32_t *edge, uint32_t *lut) {
+  const uint32_t n = fi.n_states;
+  auto entry = [&] (uint32_t e) { return fv.edge_next[e] | (fv.nb_outputs[fv.edge_next[e]] ? 0x80000000u : 0u); };
+  for (uint32_t e = 0; e < fi.n_edges; e++) {
+    edge[2 * e] = fv.edge_sym[e];
+    edge[2 * e + 1] = entry (e);
+  }
+  for (uint32_t st = 0; st < n; st++) {
+    const uint32_t b = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b;
+    uint32_t *r = rec + 8 * (size_t)st;
+    r[0] = fv.fail[st];
+    r[1] = ne;
+    r[2] = b;
+    r[3] = 0;
+    r[4] = ne >= 1 ? fv.edge_sym[b] : 0;
+    r[5] = ne >= 1 ? entry (b) : 0;
+    r[6] = ne >= 2 ? fv.edge_sym[b + 1] : 0;
+    r[7] = ne >= 2 ? entry (b + 1) : 0;
+  }
+  for (uint32_t e = 0; e < fv.row_ptr[1]; e++)
+    if (fv.edge_sym[e] < lut_size)
+      lut[fv.edge_sym[e]] = entry (e);
+}
+
+/* start-parallel kernel (dev_starts.h): trie records with terminal flags, plain edges, root table
+ * with SECOND / ALWAYS flags, first-two-edge-symbols of the root's children */
+void
+fill_starts_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, uint32_t lut_size, uint32_t *rec, uint32_t *edge, uint32_t *lut,
+                    uint32_t *pairs) {
+  const uint32_t n = fi.n_states;
+  for (uint32_t e = 0; e < fi.n_edges; e++) {
+    edge[2 * e] = fv.edge_sym[e];
+    edge[2 * e + 1] = fv.edge_next[e];
+  }
+  for (uint32_t st = 0; st < n; st++) {
+    const uint32_t b = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b;
+    uint32_t *r = rec + 8 * (size_t)st;
+    r[0] = 0;
+    r[1] = ne;
+    r[2] = b;
+    r[3] = fv.term_kw[st] != NONE ? 1u : 0u;
+    r[4] = ne >= 1 ? fv.edge_sym[b] : 0;
+    r[5] = ne >= 1 ? fv.edge_next[b] : 0;
+    r[6] = ne >= 2 ? fv.edge_sym[b + 1] : 0;
+    r[7] = ne >= 2 ? fv.edge_next[b + 1] : 0;
+  }
+  const uint32_t root_edges = fv.row_ptr[1];
+  {
+    /* the root's row in the edge table: only the symbols the root table cannot hold (the tail
+     * of the sorted row; usually nothing) -- the table itself answers for the others */
+    uint32_t beyond = 0;
+    while (beyond < root_edges && fv.edge_sym[root_edges - 1 - beyond] >= lut_size)
+      beyond++;
+    rec[1] = beyond;
+    rec[2] = root_edges - beyond;
+  }
+  for (uint32_t st = 0; st <= root_edges; st++) {
+    const uint32_t b = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b;
+    pairs[2 * st] = ne >= 1 ? fv.edge_sym[b] : 0;
+    pairs[2 * st + 1] = ne >= 2 ? fv.edge_sym[b + 1] : pairs[2 * st];
+  }
+  for (uint32_t e = 0; e < root_edges; e++)
+    if (fv.edge_sym[e] < lut_size) {
+      const uint32_t child = fv.edge_next[e];
+      const uint32_t ne = fv.row_ptr[child + 1] - fv.row_ptr[child];
+      /* keyword by itself, more edges than the pair shows, or a pair that cannot be told
+       * from "no edge" (symbol 0 twice): never sieved out */
+      const bool always = fv.term_kw[child] != NONE || ne > 2 || ne == 0;
+      lut[fv.edge_sym[e]] = child | (always ? ST_ALWAYS : 0u);
+    }
+  /* second symbols: the edges that leave the root's children (states 1 .. root_edges) */
+  for (uint32_t e = fv.row_ptr[1]; e < fv.row_ptr[root_edges + 1]; e++)
+    if (fv.edge_sym[e] < lut_size)
+      lut[fv.edge_sym[e]] |= ST_SECOND;
+}
+
+/* 4-gram sieve kernel (dev_gram.h): where its tables go and how they are keyed */
+struct GramImage {
+  bool wide, shorts;
+  uint32_t W, bloom_log2, wtab_log2, stab_log2;
+  uint32_t *bits, *g4, *rec, *edge, *g4gid; /* first-stage bits, second-stage records, trie records (depth-first), their edges, depth-4 state -> record */
+  unsigned char *nib;                      /* narrow alphabets: nibble per 3-gram */
+  uint32_t *g3, *stab;                     /* short keywords: prefix states per 3-gram (narrow) / table of tagged windows (wide) */
+};
+
+void
+fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage &G) {
+  const uint32_t n = fi.n_states;
+  uint32_t *bits = G.bits, *g4 = G.g4, *rec = G.rec, *edge = G.edge, *g4gid = G.g4gid;
+  {
+    /* records of the states of depth >= 4 in depth-first (preorder) order, subtree after
+     * subtree of the depth-4 states: the tail of a keyword is a run of consecutive 32-byte
+     * records, so a walk touches one or two cache lines instead of one per symbol */
+    std::vector<uint32_t> gid (n, 0), stack;
+    uint32_t next_gid = 0;
+    for (uint32_t root4 = fv.depth_start[4]; root4 < fv.depth_start[5]; root4++) {
+      g4gid[root4 - fv.depth_start[4]] = next_gid;
+      stack.push_back (root4);
+      while (!stack.empty ()) {
+        const uint32_t st = stack.back ();
+        stack.pop_back ();
+        gid[st] = next_gid++;
+        for (uint32_t e = fv.row_ptr[st + 1]; e-- > fv.row_ptr[st];) /* first child on top */
+          stack.push_back (fv.edge_next[e]);
+      }
+    }
+    uint32_t slots = 0;
+    for (uint32_t st = fv.depth_start[4]; st < n; st++) {
+      const uint32_t b0 = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b0;
+      uint32_t *r = rec + 8 * (size_t)gid[st];
+      r[0] = st;
+      r[1] = ne;
+      r[2] = slots;
+      r[3] = fv.term_kw[st] != NONE ? 1u : 0u;
+      r[4] = ne >= 1 ? fv.edge_sym[b0] : 0;
+      r[5] = ne >= 1 ? gid[fv.edge_next[b0]] : 0;
+      r[6] = ne >= 2 ? fv.edge_sym[b0 + 1] : 0;
+      r[7] = ne >= 2 ? gid[fv.edge_next[b0 + 1]] : 0;
+      for (uint32_t e = b0; e < b0 + ne; e++) {
+        edge[2 * (size_t)slots] = fv.edge_sym[e];
+        edge[2 * (size_t)slots + 1] = gid[fv.edge_next[e]];
+        slots++;
+      }
+    }
+  }
+  /* base-W number of the path of every state down to depth 4 (parents come first in
+   * breadth-first order); the depth-4 states are the 4-grams some keyword starts with */
+  std::vector<uint32_t> path (fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1], 0);
+  for (uint32_t st = 0; st < fv.depth_start[4]; st++)
+    for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
+      path[fv.edge_next[e]] = G.wide ? path[st] | (fv.edge_sym[e] << (8 * fv.depth[st])) /* the 4 bytes as the text holds them */
+                                        : path[st] * G.W + (fv.edge_sym[e] - fi.alpha_lo);
+  for (uint32_t st = fv.depth_start[4]; G.wide && st < fv.depth_start[5]; st++) {
+    const uint32_t win = path[st];
+    const uint32_t hb = (win * WIDE_H1) >> (32 - G.bloom_log2);
+    bits[hb >> 5] |= 1u << (hb & 31);
+    uint32_t slot = (win * WIDE_H2) >> (32 - G.wtab_log2);
+    while (g4[2 * (size_t)slot + 1])
+      slot = (slot + 1) & ((1u << G.wtab_log2) - 1);
+    g4[2 * (size_t)slot] = win;
+    g4[2 * (size_t)slot + 1] = st | (fv.term_kw[st] != NONE ? WT_TERM : 0u) | (fv.row_ptr[st + 1] > fv.row_ptr[st] ? WT_KIDS : 0u);
+  }
+  for (uint32_t st = fv.depth_start[4]; !G.wide && st < fv.depth_start[5]; st++) {
+    const uint32_t idx = path[st];
+    uint32_t mask = fv.term_kw[st] != NONE ? 0x80000000u : 0u;
+    for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
+      mask |= 1u << (fv.edge_sym[e] - fi.alpha_lo);
+    bits[idx >> 5] |= 1u << (idx & 31);
+    g4[2 * (size_t)idx] = mask;
+    g4[2 * (size_t)idx + 1] = st;
+  }
+  if (G.shorts && G.wide) {
+    uint32_t *stab = G.stab;
+    for (uint32_t st = 1; st < fv.depth_start[4]; st++) {
+      if (fv.term_kw[st] == NONE)
+        continue;
+      const uint32_t key = path[st] | (fv.depth[st] << 24);
+      const uint32_t hb = (key * WIDE_H1) >> (32 - G.bloom_log2);
+      bits[hb >> 5] |= 1u << (hb & 31);
+      uint32_t slot = (key * WIDE_H2) >> (32 - G.stab_log2);
+      while (stab[2 * (size_t)slot + 1])
+        slot = (slot + 1) & ((1u << G.stab_log2) - 1);
+      stab[2 * (size_t)slot] = key;
+      stab[2 * (size_t)slot + 1] = st;
+    }
+  }
+  if (G.shorts && !G.wide) {
+    /* a keyword of d < 4 symbols with path p covers the 3-gram indices [p * W^(3-d), (p+1) * W^(3-d)) */
+    unsigned char *nib = G.nib;
+    uint32_t *g3 = G.g3;
+    for (uint32_t st = 1; st < fv.depth_start[4]; st++) {
+      if (fv.term_kw[st] == NONE)
+        continue;
+      const uint32_t d = fv.depth[st];
+      uint32_t width = 1;
+      for (uint32_t k = d; k < 3; k++)
+        width *= G.W;
+      for (uint32_t i3 = path[st] * width; i3 < (path[st] + 1) * width; i3++) {
+        nib[i3 >> 1] |= (unsigned char)((1u << (d - 1)) << ((i3 & 1) * 4));
+        g3[4 * (size_t)i3 + (d - 1)] = st;
+      }
+    }
+  }
+}
+
+} // namespace
+
 extern "C" int
 acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   if (!flat || !out)
@@ -495,181 +687,29 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     }
   }
   memcpy (&host[o_dstart], fv.depth_start, ((size_t)fi.lmax + 2) * 4);
-  if (sparse) {
-    uint32_t *rec = reinterpret_cast<uint32_t *> (&host[o_srec]);
-    uint32_t *edge = reinterpret_cast<uint32_t *> (&host[o_sedge]);
-    uint32_t *lut = reinterpret_cast<uint32_t *> (&host[o_lut]);
-    auto entry = [&] (uint32_t e) { return fv.edge_next[e] | (fv.nb_outputs[fv.edge_next[e]] ? 0x80000000u : 0u); };
-    for (uint32_t e = 0; e < fi.n_edges; e++) {
-      edge[2 * e] = fv.edge_sym[e];
-      edge[2 * e + 1] = entry (e);
-    }
-    for (uint32_t st = 0; st < n; st++) {
-      const uint32_t b = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b;
-      uint32_t *r = rec + 8 * (size_t)st;
-      r[0] = fv.fail[st];
-      r[1] = ne;
-      r[2] = b;
-      r[3] = 0;
-      r[4] = ne >= 1 ? fv.edge_sym[b] : 0;
-      r[5] = ne >= 1 ? entry (b) : 0;
-      r[6] = ne >= 2 ? fv.edge_sym[b + 1] : 0;
-      r[7] = ne >= 2 ? entry (b + 1) : 0;
-    }
-    for (uint32_t e = 0; e < fv.row_ptr[1]; e++)
-      if (fv.edge_sym[e] < lut_size)
-        lut[fv.edge_sym[e]] = entry (e);
-  }
-  if (starts) {
-    uint32_t *rec = reinterpret_cast<uint32_t *> (&host[o_trec]);
-    uint32_t *edge = reinterpret_cast<uint32_t *> (&host[o_tedge]);
-    uint32_t *lut = reinterpret_cast<uint32_t *> (&host[o_tlut]);
-    uint32_t *pairs = reinterpret_cast<uint32_t *> (&host[o_tpairs]);
-    for (uint32_t e = 0; e < fi.n_edges; e++) {
-      edge[2 * e] = fv.edge_sym[e];
-      edge[2 * e + 1] = fv.edge_next[e];
-    }
-    for (uint32_t st = 0; st < n; st++) {
-      const uint32_t b = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b;
-      uint32_t *r = rec + 8 * (size_t)st;
-      r[0] = 0;
-      r[1] = ne;
-      r[2] = b;
-      r[3] = fv.term_kw[st] != NONE ? 1u : 0u;
-      r[4] = ne >= 1 ? fv.edge_sym[b] : 0;
-      r[5] = ne >= 1 ? fv.edge_next[b] : 0;
-      r[6] = ne >= 2 ? fv.edge_sym[b + 1] : 0;
-      r[7] = ne >= 2 ? fv.edge_next[b + 1] : 0;
-    }
-    const uint32_t root_edges = fv.row_ptr[1];
-    {
-      /* the root's row in the edge table: only the symbols the root table cannot hold (the tail
-       * of the sorted row; usually nothing) -- the table itself answers for the others */
-      uint32_t beyond = 0;
-      while (beyond < root_edges && fv.edge_sym[root_edges - 1 - beyond] >= lut_size)
-        beyond++;
-      rec[1] = beyond;
-      rec[2] = root_edges - beyond;
-    }
-    for (uint32_t st = 0; st <= root_edges; st++) {
-      const uint32_t b = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b;
-      pairs[2 * st] = ne >= 1 ? fv.edge_sym[b] : 0;
-      pairs[2 * st + 1] = ne >= 2 ? fv.edge_sym[b + 1] : pairs[2 * st];
-    }
-    for (uint32_t e = 0; e < root_edges; e++)
-      if (fv.edge_sym[e] < lut_size) {
-        const uint32_t child = fv.edge_next[e];
-        const uint32_t ne = fv.row_ptr[child + 1] - fv.row_ptr[child];
-        /* keyword by itself, more edges than the pair shows, or a pair that cannot be told
-         * from "no edge" (symbol 0 twice): never sieved out */
-        const bool always = fv.term_kw[child] != NONE || ne > 2 || ne == 0;
-        lut[fv.edge_sym[e]] = child | (always ? ST_ALWAYS : 0u);
-      }
-    /* second symbols: the edges that leave the root's children (states 1 .. root_edges) */
-    for (uint32_t e = fv.row_ptr[1]; e < fv.row_ptr[root_edges + 1]; e++)
-      if (fv.edge_sym[e] < lut_size)
-        lut[fv.edge_sym[e]] |= ST_SECOND;
-  }
+  if (sparse)
+    fill_sparse_tables (fv, fi, lut_size, reinterpret_cast<uint32_t *> (&host[o_srec]), reinterpret_cast<uint32_t *> (&host[o_sedge]),
+                        reinterpret_cast<uint32_t *> (&host[o_lut]));
+  if (starts)
+    fill_starts_tables (fv, fi, lut_size, reinterpret_cast<uint32_t *> (&host[o_trec]), reinterpret_cast<uint32_t *> (&host[o_tedge]),
+                        reinterpret_cast<uint32_t *> (&host[o_tlut]), reinterpret_cast<uint32_t *> (&host[o_tpairs]));
   if (gram) {
-    uint32_t *bits = reinterpret_cast<uint32_t *> (&host[o_g4bits]);
-    uint32_t *g4 = reinterpret_cast<uint32_t *> (&host[o_g4rec]);
-    uint32_t *rec = reinterpret_cast<uint32_t *> (&host[o_grec]);
-    uint32_t *edge = reinterpret_cast<uint32_t *> (&host[o_gedge]);
-    uint32_t *g4gid = reinterpret_cast<uint32_t *> (&host[o_g4gid]);
-    {
-      /* records of the states of depth >= 4 in depth-first (preorder) order, subtree after
-       * subtree of the depth-4 states: the tail of a keyword is a run of consecutive 32-byte
-       * records, so a walk touches one or two cache lines instead of one per symbol */
-      std::vector<uint32_t> gid (n, 0), stack;
-      uint32_t next_gid = 0;
-      for (uint32_t root4 = fv.depth_start[4]; root4 < fv.depth_start[5]; root4++) {
-        g4gid[root4 - fv.depth_start[4]] = next_gid;
-        stack.push_back (root4);
-        while (!stack.empty ()) {
-          const uint32_t st = stack.back ();
-          stack.pop_back ();
-          gid[st] = next_gid++;
-          for (uint32_t e = fv.row_ptr[st + 1]; e-- > fv.row_ptr[st];) /* first child on top */
-            stack.push_back (fv.edge_next[e]);
-        }
-      }
-      uint32_t slots = 0;
-      for (uint32_t st = fv.depth_start[4]; st < n; st++) {
-        const uint32_t b0 = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b0;
-        uint32_t *r = rec + 8 * (size_t)gid[st];
-        r[0] = st;
-        r[1] = ne;
-        r[2] = slots;
-        r[3] = fv.term_kw[st] != NONE ? 1u : 0u;
-        r[4] = ne >= 1 ? fv.edge_sym[b0] : 0;
-        r[5] = ne >= 1 ? gid[fv.edge_next[b0]] : 0;
-        r[6] = ne >= 2 ? fv.edge_sym[b0 + 1] : 0;
-        r[7] = ne >= 2 ? gid[fv.edge_next[b0 + 1]] : 0;
-        for (uint32_t e = b0; e < b0 + ne; e++) {
-          edge[2 * (size_t)slots] = fv.edge_sym[e];
-          edge[2 * (size_t)slots + 1] = gid[fv.edge_next[e]];
-          slots++;
-        }
-      }
-    }
-    /* base-W number of the path of every state down to depth 4 (parents come first in
-     * breadth-first order); the depth-4 states are the 4-grams some keyword starts with */
-    std::vector<uint32_t> path (fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1], 0);
-    for (uint32_t st = 0; st < fv.depth_start[4]; st++)
-      for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
-        path[fv.edge_next[e]] = gram_wide ? path[st] | (fv.edge_sym[e] << (8 * fv.depth[st])) /* the 4 bytes as the text holds them */
-                                          : path[st] * gW + (fv.edge_sym[e] - fi.alpha_lo);
-    for (uint32_t st = fv.depth_start[4]; gram_wide && st < fv.depth_start[5]; st++) {
-      const uint32_t win = path[st];
-      const uint32_t hb = (win * WIDE_H1) >> (32 - bloom_log2);
-      bits[hb >> 5] |= 1u << (hb & 31);
-      uint32_t slot = (win * WIDE_H2) >> (32 - wtab_log2);
-      while (g4[2 * (size_t)slot + 1])
-        slot = (slot + 1) & ((1u << wtab_log2) - 1);
-      g4[2 * (size_t)slot] = win;
-      g4[2 * (size_t)slot + 1] = st | (fv.term_kw[st] != NONE ? WT_TERM : 0u) | (fv.row_ptr[st + 1] > fv.row_ptr[st] ? WT_KIDS : 0u);
-    }
-    for (uint32_t st = fv.depth_start[4]; !gram_wide && st < fv.depth_start[5]; st++) {
-      const uint32_t idx = path[st];
-      uint32_t mask = fv.term_kw[st] != NONE ? 0x80000000u : 0u;
-      for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
-        mask |= 1u << (fv.edge_sym[e] - fi.alpha_lo);
-      bits[idx >> 5] |= 1u << (idx & 31);
-      g4[2 * (size_t)idx] = mask;
-      g4[2 * (size_t)idx + 1] = st;
-    }
-    if (gram_shorts && gram_wide) {
-      uint32_t *stab = reinterpret_cast<uint32_t *> (&host[o_stab]);
-      for (uint32_t st = 1; st < fv.depth_start[4]; st++) {
-        if (fv.term_kw[st] == NONE)
-          continue;
-        const uint32_t key = path[st] | (fv.depth[st] << 24);
-        const uint32_t hb = (key * WIDE_H1) >> (32 - bloom_log2);
-        bits[hb >> 5] |= 1u << (hb & 31);
-        uint32_t slot = (key * WIDE_H2) >> (32 - stab_log2);
-        while (stab[2 * (size_t)slot + 1])
-          slot = (slot + 1) & ((1u << stab_log2) - 1);
-        stab[2 * (size_t)slot] = key;
-        stab[2 * (size_t)slot + 1] = st;
-      }
-    }
-    if (gram_shorts && !gram_wide) {
-      /* a keyword of d < 4 symbols with path p covers the 3-gram indices [p * W^(3-d), (p+1) * W^(3-d)) */
-      unsigned char *nib = &host[o_g4bits + g3_off];
-      uint32_t *g3 = reinterpret_cast<uint32_t *> (&host[o_g3rec]);
-      for (uint32_t st = 1; st < fv.depth_start[4]; st++) {
-        if (fv.term_kw[st] == NONE)
-          continue;
-        const uint32_t d = fv.depth[st];
-        uint32_t width = 1;
-        for (uint32_t k = d; k < 3; k++)
-          width *= gW;
-        for (uint32_t i3 = path[st] * width; i3 < (path[st] + 1) * width; i3++) {
-          nib[i3 >> 1] |= (unsigned char)((1u << (d - 1)) << ((i3 & 1) * 4));
-          g3[4 * (size_t)i3 + (d - 1)] = st;
-        }
-      }
-    }
+    GramImage G{};
+    G.wide = gram_wide;
+    G.shorts = gram_shorts;
+    G.W = gW;
+    G.bloom_log2 = bloom_log2;
+    G.wtab_log2 = wtab_log2;
+    G.stab_log2 = stab_log2;
+    G.bits = reinterpret_cast<uint32_t *> (&host[o_g4bits]);
+    G.g4 = reinterpret_cast<uint32_t *> (&host[o_g4rec]);
+    G.rec = reinterpret_cast<uint32_t *> (&host[o_grec]);
+    G.edge = reinterpret_cast<uint32_t *> (&host[o_gedge]);
+    G.g4gid = reinterpret_cast<uint32_t *> (&host[o_g4gid]);
+    G.nib = &host[o_g4bits + g3_off];
+    G.g3 = reinterpret_cast<uint32_t *> (&host[o_g3rec]);
+    G.stab = reinterpret_cast<uint32_t *> (&host[o_stab]);
+    fill_gram_tables (fv, fi, G);
   }
   if (dense) {
     int rc = acm_flat_dense_rows (flat, n, entry_bytes, &host[o_dense]);
