@@ -28,6 +28,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -626,11 +627,21 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const size_t o_tedge = blob_reserve (cur, starts ? (size_t)fi.n_edges * 8 : 0);
   const size_t o_tlut = blob_reserve (cur, starts ? (size_t)lut_size * 4 + 16 : 0);
   const size_t o_tpairs = blob_reserve (cur, starts ? (size_t)n * 8 : 0); /* by state id; filled for the root's children */
-  /* 4-gram sieve kernel: byte alphabets of width <= 30 whose automaton is too big for the LDS
-   * scheme, every keyword at least 4 symbols long */
-  const char *gram_env = getenv ("ACM_GPU_GRAM"); /* 0: never; 2: also for dictionaries the LDS scheme takes (experiments) */
+  /* 4-gram sieve kernel: byte dictionaries that the LDS scheme of the dense kernel does not serve
+   * well.  That is every automaton of more than 32,768 states, and the smaller ones whose hot set
+   * outgrows LDS: the share of a uniform text's positions that land in a state without an LDS row
+   * is estimated as the sum over those states of span^-depth; above 0.2 % the continuation items
+   * swamp the dense kernel (measured on a-z: 1,250 keywords 0.13 % -> dense 0.46 ms against 0.50 ms
+   * per GiB; 1,500 keywords 0.26 % -> 0.58 against 0.51; 3,000 keywords -> 9.0 against 0.56). */
+  const char *gram_env = getenv ("ACM_GPU_GRAM"); /* 0: never; 2: whenever the dictionary qualifies (experiments) */
   const int gram_mode = gram_env ? atoi (gram_env) : 1;
-  const bool gram_big = dense && (entry_bytes == 4 || gram_mode == 2) && gram_mode != 0 && fi.lmax >= 4 && n < 0x40000000u;
+  double rowless_share = 0;
+  if (cont && fi.alpha_span > 1) {
+    for (uint32_t s = HD; s < n; s++)
+      rowless_share += pow ((double)fi.alpha_span, -(double)fv.depth[s]);
+  }
+  const bool gram_big = dense && (entry_bytes == 4 || gram_mode == 2 || rowless_share > 0.002) && gram_mode != 0 && fi.lmax >= 4 &&
+                        n < 0x40000000u;
   const bool gram_narrow = fi.width <= 30 && fi.width == fi.alpha_span + 1;
   bool gram_shorts = false; /* keywords of 1-3 symbols: the kernel's nibble table and third queue */
   for (uint32_t k = 0; k < fi.n_keywords && gram_big; k++)

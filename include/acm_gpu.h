@@ -142,8 +142,9 @@ typedef struct {
                             alignment); 2- and 4-byte symbols in 16-byte aligned buffers: 4 = start-parallel kernel
                             (root table by symbol value, every position verified independently), or
                             3 = sparse automaton walk when the environment says ACM_GPU_SPARSE=walk;
-                            5 = 4-gram sieve kernel: byte alphabets, more than 32,768 states, some keyword of 4
-                            symbols or more (ACM_GPU_GRAM=0: kernel 1 instead) */
+                            5 = 4-gram sieve kernel: byte dictionaries whose hot rows outgrow LDS (more than about
+                            1,300 keywords over a-z) with some keyword of 4 symbols or more
+                            (ACM_GPU_GRAM=0: kernel 1 instead, ACM_GPU_GRAM=2: kernel 5 whenever possible) */
   uint32_t entry_bytes;  /* dense entries: 2 or 4 */
   uint32_t width;        /* dense row width */
   uint32_t dense_rows;   /* rows resident in HBM */
