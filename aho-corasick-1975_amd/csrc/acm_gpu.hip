@@ -640,9 +640,9 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     for (uint32_t s = HD; s < n; s++)
       rowless_share += pow ((double)fi.alpha_span, -(double)fv.depth[s]);
   }
-  const bool gram_big = dense && (entry_bytes == 4 || gram_mode == 2 || rowless_share > 0.002) && gram_mode != 0 && fi.lmax >= 4 &&
+  const bool gram_big = dense && (entry_bytes == 4 || gram_mode >= 2 || rowless_share > 0.002) && gram_mode != 0 && fi.lmax >= 4 &&
                         n < 0x40000000u;
-  const bool gram_narrow = fi.width <= 30 && fi.width == fi.alpha_span + 1;
+  const bool gram_narrow = fi.width <= 30 && fi.width == fi.alpha_span + 1 && gram_mode != 3; /* 3: hashed windows always (experiments) */
   bool gram_shorts = false; /* keywords of 1-3 symbols: the kernel's nibble table and third queue */
   for (uint32_t k = 0; k < fi.n_keywords && gram_big; k++)
     gram_shorts |= fv.depth[fv.kw_state[k]] < 4;
