@@ -630,9 +630,10 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   /* 4-gram sieve kernel: byte dictionaries that the LDS scheme of the dense kernel does not serve
    * well.  That is every automaton of more than 32,768 states, and the smaller ones whose hot set
    * outgrows LDS: the share of a uniform text's positions that land in a state without an LDS row
-   * is estimated as the sum over those states of span^-depth; above 0.2 % the continuation items
-   * swamp the dense kernel (measured on a-z: 1,250 keywords 0.13 % -> dense 0.46 ms against 0.50 ms
-   * per GiB; 1,500 keywords 0.26 % -> 0.58 against 0.51; 3,000 keywords -> 9.0 against 0.56). */
+   * is estimated as the sum over those states of span^-depth; above 0.1 % the continuation items
+   * swamp the dense kernel (measured on a-z, ms per GiB, dense against 4-gram: 1,100 keywords
+   * 0.06 % -> 0.38 / 0.41; 1,250 keywords 0.13 % -> 0.46 / 0.42; 1,500 keywords 0.26 % -> 0.58 /
+   * 0.43; 3,000 keywords -> 9.0 / 0.48). */
   const char *gram_env = getenv ("ACM_GPU_GRAM"); /* 0: never; 2: whenever the dictionary qualifies (experiments) */
   const int gram_mode = gram_env ? atoi (gram_env) : 1;
   double rowless_share = 0;
@@ -640,7 +641,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     for (uint32_t s = HD; s < n; s++)
       rowless_share += pow ((double)fi.alpha_span, -(double)fv.depth[s]);
   }
-  const bool gram_big = dense && (entry_bytes == 4 || gram_mode >= 2 || rowless_share > 0.002) && gram_mode != 0 && fi.lmax >= 4 &&
+  const bool gram_big = dense && (entry_bytes == 4 || gram_mode >= 2 || rowless_share > 0.001) && gram_mode != 0 && fi.lmax >= 4 &&
                         n < 0x40000000u;
   const bool gram_narrow = fi.width <= 30 && fi.width == fi.alpha_span + 1 && gram_mode != 3; /* 3: hashed windows always (experiments) */
   bool gram_shorts = false; /* keywords of 1-3 symbols: the kernel's nibble table and third queue */

@@ -294,8 +294,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
         if (pos0 + j >= A.n)
           c[j] = K.span;
     }
-    uint32_t idx = ((c[0] * K.W + c[1]) * K.W + c[2]) * K.W + c[3];
-    uint32_t idx3 = (c[0] * K.W + c[1]) * K.W + c[2];
+    /* (24-bit multiplies: everything here is below 2^24, and v_mul_u32_u24 / v_mad_u32_u24 run at
+     * full rate where the 32-bit multiply and the 64-bit mad the compiler picks otherwise take
+     * four times as long) */
+    uint32_t idx = __umul24 (__umul24 (__umul24 (c[0], K.W) + c[1], K.W) + c[2], K.W) + c[3];
+    uint32_t idx3 = __umul24 (__umul24 (c[0], K.W) + c[1], K.W) + c[2];
     const uint32_t W3 = SHORTS ? K.W * K.W * K.W : 0u;
     /* eight positions at a time: all their table words are asked for before any is looked at
      * (slot by slot, every ds_read waited behind the queue's ds_write of the slot before it,
@@ -307,11 +310,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       for (int j = 0; j < 8; j++) {
         ix[j] = idx;
         word[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
-        idx = idx * K.W + c[8 * h + j + 4] - c[8 * h + j] * K.W4;
+        idx = __umul24 (idx, K.W) + c[8 * h + j + 4] - __umul24 (c[8 * h + j], K.W4);
         if (SHORTS) {
           ix3[j] = idx3;
           nibs[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) unsigned char *> (K.g3_off + (idx3 >> 1));
-          idx3 = idx3 * K.W + c[8 * h + j + 3] - c[8 * h + j] * W3;
+          idx3 = __umul24 (idx3, K.W) + c[8 * h + j + 3] - __umul24 (c[8 * h + j], W3);
         }
       }
       if (SHORTS) {
@@ -330,7 +333,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const bool push = (word[j] >> (ix[j] & 31u)) & 1u;
+        const bool push = __builtin_amdgcn_ubfe (word[j], ix[j], 1u) != 0; /* v_bfe_u32 (it takes the low 5 bits of the offset itself) */
         const uint64_t m = __ballot (push);
         if (m) {
           if (push)
