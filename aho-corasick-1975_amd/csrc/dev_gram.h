@@ -297,9 +297,13 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     /* (24-bit multiplies: everything here is below 2^24, and v_mul_u32_u24 / v_mad_u32_u24 run at
      * full rate where the 32-bit multiply and the 64-bit mad the compiler picks otherwise take
      * four times as long) */
-    uint32_t idx = __umul24 (__umul24 (__umul24 (c[0], K.W) + c[1], K.W) + c[2], K.W) + c[3];
-    uint32_t idx3 = __umul24 (__umul24 (c[0], K.W) + c[1], K.W) + c[2];
-    const uint32_t W3 = SHORTS ? K.W * K.W * K.W : 0u;
+    /* pair[j] = index of the symbols j, j + 1; a 4-gram index is two pairs, a 3-gram index a pair
+     * and a symbol: two multiply-adds per position instead of the three of a rolling update */
+    uint32_t pair[19];
+#pragma unroll
+    for (int j = 0; j < 19; j++)
+      pair[j] = __umul24 (c[j], K.W) + c[j + 1];
+    const uint32_t W2 = K.W * K.W;
     /* eight positions at a time: all their table words are asked for before any is looked at
      * (slot by slot, every ds_read waited behind the queue's ds_write of the slot before it,
      * which the compiler must assume to alias: 16 LDS round trips in a row per group) */
@@ -308,13 +312,13 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       uint32_t ix[8], word[8], ix3[SHORTS ? 8 : 1], nibs[SHORTS ? 8 : 1];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
+        const uint32_t idx = __umul24 (pair[8 * h + j], W2) + pair[8 * h + j + 2];
         ix[j] = idx;
         word[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
-        idx = __umul24 (idx, K.W) + c[8 * h + j + 4] - __umul24 (c[8 * h + j], K.W4);
         if (SHORTS) {
+          const uint32_t idx3 = __umul24 (pair[8 * h + j], K.W) + c[8 * h + j + 2];
           ix3[j] = idx3;
           nibs[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) unsigned char *> (K.g3_off + (idx3 >> 1));
-          idx3 = __umul24 (idx3, K.W) + c[8 * h + j + 3] - __umul24 (c[8 * h + j], W3);
         }
       }
       if (SHORTS) {
