@@ -14,8 +14,9 @@
  * (end_pos ascending, then j ascending == length descending).
  *
  * All of it runs on the GPU as hand-written HIP; there is NO CPU fallback: a machine the GPU
- * path cannot take (comparator other than ACM_CMP_DEFAULT, symbol size not in {1,2,4}) or a
- * missing device is reported as an error code and the caller keeps using the per-symbol API.
+ * path cannot take (symbol size not in {1,2,4,8}; a comparator other than ACM_CMP_DEFAULT unless
+ * the plan is made with acm_gpu_plan_create_classes) or a missing device is reported as an error
+ * code and the caller keeps using the per-symbol API.
  *
  * Plain C ABI: pointers and sizes only.  `stream` arguments are a hipStream_t passed as void *
  * (NULL = the default stream); `d_` pointers are device memory on the plan's device.
