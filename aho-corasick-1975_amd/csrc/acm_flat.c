@@ -157,9 +157,9 @@ flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint3
     uint32_t nk = 0;
     for (uint32_t h = 0, t = 1; h < t; h++) {
       struct _ac_state *st = order[h];
-      for (uint32_t i = 0; i < st->nkids; i++) {
-        keys[nk++] = symbol_value64 (st->kids[i]->letter);
-        order[t++] = st->kids[i];
+      for (uint32_t i = 0; i < ACM_NKIDS (st); i++) {
+        keys[nk++] = symbol_value64 (ACM_KID (st, i)->letter);
+        order[t++] = ACM_KID (st, i);
       }
     }
     qsort (keys, nk, sizeof *keys, u64_cmp);
@@ -172,8 +172,8 @@ flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint3
   while (head < tail) {
     struct _ac_state *s = order[head];
     f->row_ptr[head] = edges;
-    for (uint32_t i = 0; i < s->nkids; i++) {
-      struct _ac_state *k = s->kids[i];
+    for (uint32_t i = 0; i < ACM_NKIDS (s); i++) {
+      struct _ac_state *k = ACM_KID (s, i);
       newid[k->id] = tail;
       f->edge_sym[edges] = sym_bytes == 8 ? key_rank1 (f->keys64, f->n_keys64, symbol_value64 (k->letter))
                                           : symbol_value (k->letter, sym_bytes);
@@ -185,12 +185,12 @@ flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint3
       edges++;
       order[tail++] = k;
     }
-    if (sym_bytes > 1 && s->nkids > 1 && !class_map) { /* class ids already ascend in comparator order */
+    if (sym_bytes > 1 && ACM_NKIDS (s) > 1 && !class_map) { /* class ids already ascend in comparator order */
       /* the comparator orders multi-byte symbols by memcmp; the device bisects rows by numeric
        * value, so re-order this row (and the ids just handed out) by value */
-      if (sort_row_by_value (f->edge_sym + f->row_ptr[head], order + f->edge_next[f->row_ptr[head]], s->nkids))
+      if (sort_row_by_value (f->edge_sym + f->row_ptr[head], order + f->edge_next[f->row_ptr[head]], ACM_NKIDS (s)))
         goto nomem;
-      for (uint32_t i = 0; i < s->nkids; i++)
+      for (uint32_t i = 0; i < ACM_NKIDS (s); i++)
         newid[order[f->edge_next[f->row_ptr[head]] + i]->id] = f->edge_next[f->row_ptr[head]] + i;
     }
     head++;

@@ -902,6 +902,17 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   I.streams = p->streams;
   I.table_bytes = cur;
 
+/* a failure from here on must not leak the plan built so far */
+#define PLAN_TRY(expr)                                                                             \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      fprintf (stderr, "acm_gpu: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString (_e), __FILE__, \
+               __LINE__);                                                                          \
+      acm_gpu_plan_destroy (p);                                                                    \
+      return ACM_GPU_E_HIP;                                                                        \
+    }                                                                                              \
+  } while (0)
   if (sparse) {
     I.lds_bytes = p->starts ? p->starts_lds_bytes : p->sparse_lds_bytes;
     I.block_threads = SPARSE_THREADS;
@@ -909,21 +920,21 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     I.streams = p->starts ? 1 : SPARSE_S;
     I.chunk_bytes = 128;
     for (int co = 0; co < 2; co++) {
-      HIP_TRY (hipFuncSetAttribute (sparse_kernel_ptr (fi.sym_bytes, p->sparse_lut_lds, co != 0),
+      PLAN_TRY (hipFuncSetAttribute (sparse_kernel_ptr (fi.sym_bytes, p->sparse_lut_lds, co != 0),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->sparse_lds_bytes));
       if (p->starts)
-        HIP_TRY (hipFuncSetAttribute (starts_kernel_ptr (fi.sym_bytes, p->starts_lut_lds, co != 0),
+        PLAN_TRY (hipFuncSetAttribute (starts_kernel_ptr (fi.sym_bytes, p->starts_lut_lds, co != 0),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->starts_lds_bytes));
     }
   }
   if (p->gram) {
     for (int co = 0; co < 2; co++)
-      HIP_TRY (hipFuncSetAttribute (gram_kernel_ptr (co != 0, p->gram_shorts, p->gram_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
+      PLAN_TRY (hipFuncSetAttribute (gram_kernel_ptr (co != 0, p->gram_shorts, p->gram_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)p->gram_lds_bytes));
   }
   if (dense) {
     for (int co = 0; co < 2; co++)
-      HIP_TRY (hipFuncSetAttribute (dense_kernel_ptr (entry_bytes, p->chunk, p->streams, co != 0),
+      PLAN_TRY (hipFuncSetAttribute (dense_kernel_ptr (entry_bytes, p->chunk, p->streams, co != 0),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)I.lds_bytes));
   }
   if (interned) {
@@ -967,9 +978,10 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       acm_gpu_plan_destroy (p);
       return ACM_GPU_E_NOMEM;
     }
-    HIP_TRY (hipFuncSetAttribute (reinterpret_cast<const void *> (&classmap_kernel),
+    PLAN_TRY (hipFuncSetAttribute (reinterpret_cast<const void *> (&classmap_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 2));
   }
+#undef PLAN_TRY
   *out = p;
   return ACM_GPU_OK;
 }
@@ -1704,8 +1716,12 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
       if (!rc && stop)
         HIP_TRY (hipEventRecord (stop, st));
     }
-    if (rc)
+    if (rc) {
+      /* earlier segments may have left a partial running total and expand ticket behind */
+      if (use_dense && p->d_total)
+        (void)hipMemsetAsync (p->d_total, 0, 16, st);
       return rc;
+    }
   }
   return ACM_GPU_OK;
 }
@@ -1790,7 +1806,9 @@ acm_gpu_stream_open (ACMPlan *plan, uint64_t max_piece_symbols, uint64_t record_
 
 /* Feeds the next n_symbols of the stream from HOST memory (pinned memory makes the copy truly
  * asynchronous).  Returns as soon as the copy and the scan are enqueued; `text` must stay
- * untouched until the next feed of the same parity, acm_gpu_stream_finish or _sync. */
+ * untouched until the second next feed or acm_gpu_stream_finish has returned: before a slot is
+ * filled again the host waits for the copy that filled it two pieces ago, so by the time feed k
+ * returns the buffers of the pieces up to k - 2 have been read. */
 extern "C" int
 acm_gpu_stream_feed (ACMStream *s, const void *text, uint64_t n_symbols) {
   if (!s || (n_symbols && !text))
@@ -1804,8 +1822,10 @@ acm_gpu_stream_feed (ACMStream *s, const void *text, uint64_t n_symbols) {
     unsigned char *piece_at = s->slot[cur] + s->halo * s->sb;
     /* the slot is free once the scan that used it two pieces ago is done and the previous piece
      * has taken its context from the slot's tail */
-    if (s->pieces >= 2)
+    if (s->pieces >= 2) {
+      HIP_TRY (hipEventSynchronize (s->copied[cur])); /* the caller may now reuse that piece's buffer */
       HIP_TRY (hipStreamWaitEvent (s->copy, s->scanned[cur], 0));
+    }
     if (s->pieces >= 1)
       HIP_TRY (hipStreamWaitEvent (s->copy, s->tail_read[cur], 0));
     HIP_TRY (hipMemcpyAsync (piece_at, src, (size_t)n * s->sb, hipMemcpyHostToDevice, s->copy));
@@ -2028,7 +2048,7 @@ acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
     std::vector<uint32_t> sym;
     int rc = ACM_GPU_OK;
     for (uint32_t k = M.n_keywords; k < nk && rc == ACM_GPU_OK; k++) {
-      rc = acm_get_keyword (machine, k, &h);
+      rc = acm_internal_get_keyword (machine, k, &h); /* the machine lock is held */
       if (rc)
         break;
       sym.resize (h.length);
@@ -2055,7 +2075,8 @@ acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
     plan->generation = gen;
     return ACM_GPU_OK;
   }
-  /* rebuild behind the same handle */
+  /* rebuild behind the same handle (`gen` was read before the snapshot: keywords inserted while
+   * it is taken leave the plan stale, never wrongly fresh) */
   ACMPlan *fresh = nullptr;
   int rc = plan->d_classlut ? acm_gpu_plan_create_classes (machine, plan->class_sym_bytes, plan->device, &fresh)
                             : acm_gpu_plan_create (machine, plan->device, &fresh);
@@ -2074,30 +2095,43 @@ acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
   return ACM_GPU_OK;
 }
 
+namespace {
+/* acm_release drops the cached plan through this hook: set once, when the library is loaded */
+struct PlanDropperInit {
+  PlanDropperInit () { acm_internal_plan_dropper = drop_cached_plan; }
+} plan_dropper_init;
+} // namespace
+
+/* The reference lets many threads work on one shared machine (README.md:364); the cached plan and
+ * its scratch buffers serve one scan at a time, so concurrent acm_scan calls on one machine queue
+ * up on the machine's plan lock (threads that want to scan in parallel make a plan each). */
 extern "C" int
 acm_scan (ACMachine *machine, const void *text, uint64_t n_symbols, ACMRecord *records, uint64_t capacity, uint64_t *n_found) {
   if (!machine || !n_found)
     return ACM_GPU_E_ARG;
-  acm_internal_plan_dropper = drop_cached_plan;
+  acm_internal_plan_lock (machine);
   void **slot = acm_internal_plan_slot (machine);
   ACMPlan *plan = static_cast<ACMPlan *> (*slot);
-  const uint64_t gen = acm_internal_generation (machine);
-  if (plan && plan->generation != gen) {
-    int rc = acm_gpu_plan_update (plan, machine);
-    if (rc)
-      return rc;
-  }
-  if (!plan) {
+  int rc = ACM_GPU_OK;
+  if (plan && plan->generation != acm_internal_generation (machine))
+    rc = acm_gpu_plan_update (plan, machine);
+  if (!rc && !plan) {
     int device = 0;
     if (const char *e = getenv ("ACM_GPU_DEVICE"))
       device = atoi (e);
-    int rc = acm_gpu_plan_create (machine, device, &plan);
-    if (rc)
-      return rc;
-    plan->generation = gen;
-    *slot = plan;
+    /* keywords inserted while the tables are being made are picked up by the next call: the
+     * generation is read first */
+    const uint64_t gen = acm_internal_generation (machine);
+    rc = acm_gpu_plan_create (machine, device, &plan);
+    if (!rc) {
+      plan->generation = gen;
+      *slot = plan;
+    }
   }
-  return acm_gpu_scan_host (plan, text, n_symbols, 0, 0, records, capacity, n_found);
+  if (!rc)
+    rc = acm_gpu_scan_host (plan, text, n_symbols, 0, 0, records, capacity, n_found);
+  acm_internal_plan_unlock (machine);
+  return rc;
 }
 
 #ifdef ACM_DIAG

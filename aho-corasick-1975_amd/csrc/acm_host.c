@@ -38,6 +38,13 @@ struct slab {
   struct _ac_state states[SLAB_STATES];
 };
 
+/* an outgrown block kept until acm_release (blocks double, so all of them together are smaller
+ * than the live ones) */
+struct garbage {
+  struct garbage *next;
+  void *block;
+};
+
 struct _ac_machine {
   struct _ac_state *root;
   size_t nb_keywords;
@@ -48,7 +55,9 @@ struct _ac_machine {
   DESTROY_TYPE letter_dtor;
   struct slab *slabs;
   mtx_t lock;
+  mtx_t plan_lock; /* users of the cached device plan (acm_scan), one at a time */
   void *plan; /* cached device plan, see acm_gpu.hip */
+  struct garbage *garbage; /* outgrown edge blocks: lock-free readers may still hold them */
   struct _ac_state **keywords; /* keyword_id -> terminal state (acm_get_keyword) */
   size_t keywords_cap;
 };
@@ -99,10 +108,26 @@ void
 acm_internal_unlock (ACMachine *m) {
   ACM_REQUIRE (mtx_unlock (&m->lock) == thrd_success, "");
 }
+void
+acm_internal_plan_lock (ACMachine *m) {
+  ACM_REQUIRE (mtx_lock (&m->plan_lock) == thrd_success, "");
+}
+void
+acm_internal_plan_unlock (ACMachine *m) {
+  ACM_REQUIRE (mtx_unlock (&m->plan_lock) == thrd_success, "");
+}
 void **
 acm_internal_plan_slot (ACMachine *m) {
   return &m->plan;
 }
+
+/* Readers (acm_match, acm_get_match) take no lock -- the reference's threading model: many
+ * threads, one shared machine, one cursor per thread, insertions in between (README.md:364,
+ * aho_corasick.c:81).  Writers hold the machine lock and publish with release stores; readers use
+ * acquire loads of the fields a writer may change under them (fail, nb_outputs, terminal, the
+ * edge block and its sequence lock). */
+#define LOAD(p) __atomic_load_n ((p), __ATOMIC_ACQUIRE)
+#define STORE(p, v) __atomic_store_n ((p), (v), __ATOMIC_RELEASE)
 
 /* ------------------------------------------------------------------ states */
 static struct _ac_state *
@@ -123,25 +148,75 @@ state_alloc (ACMachine *m) {
   return s;
 }
 
-/* bisection among the children of s; *at = where a missing letter would be inserted */
+/* bisection among the children of s; *at = where a missing letter would be inserted.
+ * Safe beside a writer: the snapshot is retried if an insertion into this very state ran
+ * meanwhile (sequence lock), and a replaced block stays allocated. */
 static inline struct _ac_state *
 child_find (const struct _ac_state *s, const void *letter, uint32_t *at) {
   const ACMachine *m = s->machine;
-  uint32_t lo = 0, hi = s->nkids;
-  while (lo < hi) {
-    uint32_t mid = lo + (hi - lo) / 2;
-    struct _ac_state *k = s->kids[mid];
-    int c = m->cmp (letter, k->letter, m->cmp_arg);
-    if (c == 0)
-      return k;
-    if (c < 0)
-      hi = mid;
-    else
-      lo = mid + 1;
+  for (;;) {
+    const uint32_t v0 = LOAD (&s->kver);
+    if (v0 & 1u)
+      continue; /* an insertion is shifting the entries right now */
+    const struct _ac_kidvec *kv = LOAD (&s->kids);
+    uint32_t lo = 0, hi = kv ? __atomic_load_n (&kv->n, __ATOMIC_RELAXED) : 0;
+    struct _ac_state *found = 0;
+    while (lo < hi) {
+      uint32_t mid = lo + (hi - lo) / 2;
+      struct _ac_state *k = LOAD (&kv->v[mid]);
+      int c = m->cmp (letter, k->letter, m->cmp_arg);
+      if (c == 0) {
+        found = k;
+        break;
+      }
+      if (c < 0)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    __atomic_thread_fence (__ATOMIC_ACQUIRE);
+    if (__atomic_load_n (&s->kver, __ATOMIC_RELAXED) != v0)
+      continue;
+    if (!found && at)
+      *at = lo;
+    return found;
   }
-  if (at)
-    *at = lo;
-  return 0;
+}
+
+/* writer, machine lock held: child k goes to position `at` of n's edges */
+static void
+child_insert (struct _ac_state *n, uint32_t at, struct _ac_state *k) {
+  ACMachine *m = n->machine;
+  struct _ac_kidvec *kv = n->kids;
+  const uint32_t cnt = kv ? kv->n : 0;
+  if (!kv || cnt == kv->cap) {
+    /* a fresh block, published whole; the old one goes to the machine's garbage */
+    const uint32_t cap = cnt ? 2 * cnt : 2;
+    struct _ac_kidvec *nv = malloc (sizeof *nv + cap * sizeof nv->v[0]);
+    struct garbage *g = kv ? malloc (sizeof *g) : 0;
+    ACM_REQUIRE (nv && (g || !kv), "Out of memory.");
+    nv->cap = cap;
+    nv->n = cnt + 1;
+    if (at)
+      memcpy (nv->v, kv->v, at * sizeof nv->v[0]);
+    nv->v[at] = k;
+    if (cnt > at)
+      memcpy (nv->v + at + 1, kv->v + at, (cnt - at) * sizeof nv->v[0]);
+    STORE (&n->kids, nv);
+    if (kv) {
+      g->block = kv;
+      g->next = m->garbage;
+      m->garbage = g;
+    }
+    return;
+  }
+  __atomic_store_n (&n->kver, n->kver + 1, __ATOMIC_RELAXED); /* odd: readers wait */
+  __atomic_thread_fence (__ATOMIC_RELEASE);
+  for (uint32_t i = cnt; i > at; i--)
+    __atomic_store_n (&kv->v[i], kv->v[i - 1], __ATOMIC_RELAXED);
+  STORE (&kv->v[at], k);
+  __atomic_store_n (&kv->n, cnt + 1, __ATOMIC_RELAXED);
+  STORE (&n->kver, n->kver + 1);
 }
 
 /* delta(s, letter) of the automaton WITHOUT root self-loops: goto if defined, else down the
@@ -152,9 +227,10 @@ automaton_step (const struct _ac_state *s, const void *letter) {
     const struct _ac_state *k = child_find (s, letter, 0);
     if (k)
       return k;
-    if (!s->fail) /* only the root has no failure link */
+    const struct _ac_state *f = LOAD (&s->fail);
+    if (!f) /* only the root has no failure link */
       return s;
-    s = s->fail;
+    s = f;
   }
 }
 
@@ -191,7 +267,8 @@ walk_push (struct walk *w, struct _ac_state *s) {
   w->v[w->n++] = s;
 }
 
-/* New leaf `leaf` = child of n on letter c has just been linked into the goto tree.
+/* New leaf `leaf` = child of n on letter c, about to be linked into the goto tree (it becomes
+ * reachable only afterwards, complete: child_insert).
  * Failure maintenance (Meyer 1985; reference :194-208, :211-239, :253-265):
  *   f(leaf) = delta(f(n), c), or the root when n is the root;
  *   every existing node x.c whose longest proper suffix in the trie has just become `leaf` is
@@ -225,7 +302,7 @@ link_failure_of_new_leaf (struct _ac_state *n, struct _ac_state *leaf) {
       /* old f(xc) == f(leaf): both are the longest suffix shorter than leaf, so nb_outputs(xc)
        * is unchanged by the re-pointing. */
       inv_del (xc->fail, xc);
-      xc->fail = leaf;
+      STORE (&xc->fail, leaf);
       inv_add (leaf, xc);
     }
     free (todo.v);
@@ -245,6 +322,7 @@ acm_create (CMP_TYPE cmp, void *cmp_arg, DESTROY_TYPE dtor) {
   m->letter_dtor = dtor;
   m->root = state_alloc (m);
   ACM_REQUIRE (mtx_init (&m->lock, mtx_plain) == thrd_success, "Out of memory.");
+  ACM_REQUIRE (mtx_init (&m->plan_lock, mtx_plain) == thrd_success, "Out of memory.");
   return m;
 }
 
@@ -267,7 +345,14 @@ acm_release (ACMachine *machine) {
     free (sl);
     sl = next;
   }
+  for (struct garbage *g = machine->garbage; g;) {
+    struct garbage *next = g->next;
+    free (g->block);
+    free (g);
+    g = next;
+  }
   mtx_destroy (&machine->lock);
+  mtx_destroy (&machine->plan_lock);
   free (machine->keywords);
   free (machine);
 }
@@ -294,15 +379,8 @@ acm_insert_letter_of_keyword (ACState **state, void *letter) {
     k->parent = n;
     k->letter = letter;
     k->depth = n->depth + 1;
-    if (n->nkids == n->capkids) {
-      n->capkids = n->capkids ? 2 * n->capkids : 2;
-      n->kids = realloc (n->kids, n->capkids * sizeof *n->kids);
-      ACM_REQUIRE (n->kids, "Out of memory.");
-    }
-    memmove (n->kids + at + 1, n->kids + at, (n->nkids - at) * sizeof *n->kids);
-    n->kids[at] = k;
-    n->nkids++;
     link_failure_of_new_leaf (n, k);
+    child_insert (n, at, k);
     m->generation++;
   }
   *state = k;
@@ -316,19 +394,13 @@ acm_insert_end_of_keyword (ACState **state, void *value, void (*dtor) (void *)) 
   ACMachine *m = n->machine;
   ACM_REQUIRE (mtx_lock (&m->lock) == thrd_success, "");
   ACM_REQUIRE (n != m->root, "acm_insert_letter_of_keyword should be called first.");
+  void *previous = n->value;
+  if (!previous) { /* first non-NULL value wins, reference :357-359 */
+    n->value_dtor = dtor;
+    if (value)
+      STORE (&n->value, value);
+  }
   if (!n->terminal) {
-    /* one more keyword ends at n and at every state that has n as a suffix, i.e. the whole
-     * failure subtree of n (reference enter_output, :330-338) */
-    struct walk todo = { 0 };
-    walk_push (&todo, n);
-    while (todo.n) {
-      struct _ac_state *x = todo.v[--todo.n];
-      x->nb_outputs++;
-      for (uint32_t i = 0; i < x->ninv; i++)
-        walk_push (&todo, x->inv[i]);
-    }
-    free (todo.v);
-    n->terminal = 1;
     if (m->nb_keywords == m->keywords_cap) {
       m->keywords_cap = m->keywords_cap ? 2 * m->keywords_cap : 64;
       m->keywords = realloc (m->keywords, m->keywords_cap * sizeof *m->keywords);
@@ -336,12 +408,21 @@ acm_insert_end_of_keyword (ACState **state, void *value, void (*dtor) (void *)) 
     }
     m->keywords[m->nb_keywords] = n;
     n->rank = (uint32_t)m->nb_keywords++;
+    /* the terminal mark first, then the counts: a reader that sees a count sees the terminal
+     * states acm_get_match will look for down the failure chain */
+    STORE (&n->terminal, 1);
+    /* one more keyword ends at n and at every state that has n as a suffix, i.e. the whole
+     * failure subtree of n (reference enter_output, :330-338) */
+    struct walk todo = { 0 };
+    walk_push (&todo, n);
+    while (todo.n) {
+      struct _ac_state *x = todo.v[--todo.n];
+      STORE (&x->nb_outputs, x->nb_outputs + 1);
+      for (uint32_t i = 0; i < x->ninv; i++)
+        walk_push (&todo, x->inv[i]);
+    }
+    free (todo.v);
     m->generation++;
-  }
-  void *previous = n->value;
-  if (!n->value) { /* first non-NULL value wins, reference :357-359 */
-    n->value = value;
-    n->value_dtor = dtor;
   }
   *state = m->root;
   ACM_REQUIRE (mtx_unlock (&m->lock) == thrd_success, "");
@@ -351,7 +432,7 @@ acm_insert_end_of_keyword (ACState **state, void *value, void (*dtor) (void *)) 
 size_t
 acm_match (const ACState **state, const void *letter) {
   ACM_REQUIRE (state && *state && letter, "Invalid null state or letter.");
-  return (*state = automaton_step (*state, letter))->nb_outputs;
+  return LOAD (&(*state = automaton_step (*state, letter))->nb_outputs);
 }
 
 void
@@ -373,12 +454,12 @@ void
 acm_get_match (const ACState *state, size_t index, MatchHolder *matcher) {
   ACM_REQUIRE (state, "Invalid null state.");
   ACM_REQUIRE (state->parent, "acm_match should be called first and acm_matcher_init called on the MatchHolder.");
-  ACM_REQUIRE (index < state->nb_outputs, "Index out of bounds.");
+  ACM_REQUIRE (index < LOAD (&state->nb_outputs), "Index out of bounds.");
   /* index-th keyword-terminal state along the failure chain, nearest (= longest) first
    * (reference :459-466) */
   const struct _ac_state *t = state;
-  for (size_t seen = 0;; t = t->fail) {
-    if (t->terminal && seen++ == index)
+  for (size_t seen = 0;; t = LOAD (&t->fail)) {
+    if (LOAD (&t->terminal) && seen++ == index)
       break;
   }
   if (!matcher)
@@ -389,13 +470,25 @@ acm_get_match (const ACState *state, size_t index, MatchHolder *matcher) {
   size_t k = matcher->length;
   for (const struct _ac_state *s = t; s->parent; s = s->parent)
     matcher->letters[--k] = s->letter;
-  matcher->value = t->value;
+  matcher->value = LOAD (&t->value);
 }
 
 /* What acm_get_match would have put into the holder for a record of the bulk scan: the
  * dictionary's letters, the length and the value of keyword `keyword_id` (include/acm_gpu.h). */
 int
 acm_get_keyword (const ACMachine *machine, uint32_t keyword_id, MatchHolder *matcher) {
+  if (!machine || !matcher)
+    return ACM_GPU_E_ARG;
+  /* the keyword table may be moved by a concurrent acm_insert_end_of_keyword */
+  ACMachine *m = (ACMachine *)machine;
+  acm_internal_lock (m);
+  const int rc = acm_internal_get_keyword (machine, keyword_id, matcher);
+  acm_internal_unlock (m);
+  return rc;
+}
+
+int
+acm_internal_get_keyword (const ACMachine *machine, uint32_t keyword_id, MatchHolder *matcher) {
   if (!machine || !matcher || keyword_id >= machine->nb_keywords)
     return ACM_GPU_E_ARG;
   const struct _ac_state *t = machine->keywords[keyword_id];
@@ -439,8 +532,8 @@ acm_foreach_keyword (const ACMachine *machine, void (*operator_) (MatchHolder)) 
       MatchHolder k = { .letters = letters, .length = f->s->depth, .value = f->s->value };
       operator_ (k);
     }
-    if (f->next_kid < f->s->nkids) {
-      const struct _ac_state *kid = f->s->kids[f->next_kid++];
+    if (f->next_kid < ACM_NKIDS (f->s)) {
+      const struct _ac_state *kid = ACM_KID (f->s, f->next_kid++);
       if (top == cap) {
         cap *= 2;
         st = realloc (st, cap * sizeof *st);
@@ -462,8 +555,8 @@ acm_foreach_keyword (const ACMachine *machine, void (*operator_) (MatchHolder)) 
  * next ones start a new line indented to their parent's column with an 'L' elbow. */
 static void
 print_subtree (const struct _ac_state *s, FILE *out, int *col, int indent, PRINT_TYPE printer) {
-  for (uint32_t i = 0; i < s->nkids; i++) {
-    const struct _ac_state *k = s->kids[i];
+  for (uint32_t i = 0; i < ACM_NKIDS (s); i++) {
+    const struct _ac_state *k = ACM_KID (s, i);
     if (indent < *col) {
       *col = 0;
       fprintf (out, "\n");
