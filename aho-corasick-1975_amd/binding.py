@@ -334,18 +334,22 @@ class Machine:
         self.lmax = max(self.lmax, int(arr.size))
         return L.acm_insert_end_of_keyword(C.byref(cur), value, None)
 
-    def add_keywords_packed(self, data, offsets):
+    def add_keywords_packed(self, data, offsets, ids_as_values=False):
+        """ids_as_values: register value = (void *)(keyword_id + 1) with every keyword, so that a
+        caller of the per-symbol API can tell the keywords apart (the reference has no keyword id;
+        its MatchHolder.value is the only per-keyword datum, aho_corasick.h:23-28)."""
         data = self._symbols(data)
         self._keep.append(data)
         L = self.L
         base, ss = data.ctypes.data, self.sym_size
         ins, end, init = L.acm_insert_letter_of_keyword, L.acm_insert_end_of_keyword, L.acm_initiate
+        nbk = L.acm_nb_keywords
         for k in range(len(offsets) - 1):
             cur = C.c_void_p(init(self.handle))
             ref = C.byref(cur)
             for i in range(int(offsets[k]), int(offsets[k + 1])):
                 ins(ref, base + i * ss)
-            end(ref, None, None)
+            end(ref, (nbk(self.handle) + 1) if ids_as_values else None, None)
             self.lmax = max(self.lmax, int(offsets[k + 1] - offsets[k]))
 
     @property

@@ -217,6 +217,11 @@ struct ACMPlan {
   uint32_t regions = 0, region_items = 0;
   uint64_t segment = SEGMENT;
   uint64_t generation = 0; /* for the machine-cached plan */
+  /* ACM_GPU_EXPAND (experiments): 2 = expand_items_once_kernel, one atomic per block (default:
+   * config 2 step 0.3202 -> 0.3182 ms); 0 = expand_items_kernel, one atomic per round of 1024
+   * items; 1 = no parking, every wave expands its own queue inside the scan kernel (measured
+   * 0.277 -> 0.427 ms on the scan kernel: the walks stall the wave) */
+  int expand_mode = 2;
   int cu_count = 0;
   /* timing */
   bool timing = false;
@@ -555,6 +560,8 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   p->text_sym_bytes = interned ? 8 : fi.sym_bytes;
   p->cu_count = prop.multiProcessorCount;
 
+  if (const char *e = getenv ("ACM_GPU_EXPAND"))
+    p->expand_mode = atoi (e);
   if (const char *e = getenv ("ACM_GPU_SEGMENT_LOG2")) {
     const int lg = atoi (e);
     if (lg >= 12 && lg <= 31)
@@ -1169,7 +1176,7 @@ launch_expand_hits (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, hipStre
 
 template <bool COUNT_ONLY>
 int
-launch_starts (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
+launch_starts (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop) {
   const uint32_t group = WAVE * (16 / p->finfo.sym_bytes); /* symbols per 1 KiB group */
   const uint32_t ngroups = (uint32_t)(((uint64_t)a.n + group - 1) / group);
   uint32_t grid = p->info.grid_blocks;
@@ -1196,6 +1203,8 @@ launch_starts (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
   void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
   HIP_TRY (hipLaunchKernel (starts_kernel_ptr (p->finfo.sym_bytes, p->starts_lut_lds, COUNT_ONLY), dim3 (grid),
                             dim3 (SPARSE_THREADS), args, p->starts_lds_bytes, st));
+  if (stop) /* the timing brackets the scan kernel alone, as for the dense kernel */
+    HIP_TRY (hipEventRecord (stop, st));
   if (!COUNT_ONLY)
     launch_expand_hits (p, E, grid * wpb, st);
   return ACM_GPU_OK;
@@ -1203,7 +1212,7 @@ launch_starts (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
 
 template <bool COUNT_ONLY>
 int
-launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
+launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop) {
   const uint32_t group = WAVE * 16;
   const uint32_t ngroups = (uint32_t)(((uint64_t)a.n + group - 1) / group);
   uint32_t grid = (uint32_t)p->cu_count;
@@ -1228,6 +1237,8 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
   void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
   HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts, p->gram_wide), dim3 (grid), dim3 (SPARSE_THREADS), args,
                             p->gram_lds_bytes, st));
+  if (stop)
+    HIP_TRY (hipEventRecord (stop, st));
   if (!COUNT_ONLY)
     launch_expand_hits (p, E, grid * wpb, st);
   return ACM_GPU_OK;
@@ -1306,6 +1317,16 @@ launch_expand (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, const Expand
 template <bool CONT, bool COUNT_ONLY>
 void
 launch_expand_cfg (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, const ExpandTail &tail, hipStream_t st) {
+  if (p->expand_mode == 1) { /* nothing was parked: one block hands the total over */
+    launch_expand<CONT, COUNT_ONLY, 1024, 16> (p, E, 16, tail, st);
+    return;
+  }
+  if (p->expand_mode == 2) {
+    const dim3 g ((regions_used + 15) / 16);
+    hipLaunchKernelGGL ((expand_items_once_kernel<CONT, COUNT_ONLY, 1024, 16, 4>), g, dim3 (1024), 0, st, E,
+                        static_cast<const uint2 *> (p->d_items), p->region_items, p->d_fill, tail);
+    return;
+  }
   /* 1024 threads per 16 regions (one block per CU on config 2) measured best: 41 us against 47
    * for 8 regions and 62 for 32 (fewer, larger blocks: too few items in flight; more, smaller
    * blocks: the single record counter's atomic rate becomes the limit) */
@@ -1332,8 +1353,9 @@ launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
   a.pool_ctr = p->d_pool_ctr + (p->launch_seq & 1) * POOL_CLASSES * POOL_CTR_STRIDE;
   a.pool_reset = p->d_pool_ctr + ((p->launch_seq & 1) ^ 1) * POOL_CLASSES * POOL_CTR_STRIDE;
   p->launch_seq++;
+  void *no_items = nullptr;
   void *args[] = { &p->K, const_cast<EmitCtx *> (&E), &a, &p->d_dense, &p->d_lds_image, &p->lds_image_bytes, &a.text,
-                   &p->d_items, &p->region_items, &p->d_fill, &p->d_dstart };
+                   p->expand_mode == 1 ? &no_items : &p->d_items, &p->region_items, &p->d_fill, &p->d_dstart };
   HIP_TRY (hipLaunchKernel (dense_kernel_ptr (p->entry_bytes, p->chunk, p->streams, COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), args,
                             p->info.lds_bytes, st));
   if (stop)
@@ -1706,15 +1728,17 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
       a.range_begin = 0;
       a.range_end = a.n;
       if (p->gram)
-        rc = launch_gram<COUNT_ONLY> (p, E, a, st);
+        rc = launch_gram<COUNT_ONLY> (p, E, a, st, stop);
       else if (p->starts && (reinterpret_cast<uintptr_t> (a.text) & 15) == 0)
-        rc = launch_starts<COUNT_ONLY> (p, E, a, st);
-      else if (p->sparse && (reinterpret_cast<uintptr_t> (a.text) & 15) == 0)
-        rc = launch_sparse<COUNT_ONLY> (p, E, a, st);
-      else
-        rc = launch_csr<COUNT_ONLY> (p, E, a, st);
-      if (!rc && stop)
-        HIP_TRY (hipEventRecord (stop, st));
+        rc = launch_starts<COUNT_ONLY> (p, E, a, st, stop);
+      else {
+        if (p->sparse && (reinterpret_cast<uintptr_t> (a.text) & 15) == 0)
+          rc = launch_sparse<COUNT_ONLY> (p, E, a, st);
+        else
+          rc = launch_csr<COUNT_ONLY> (p, E, a, st);
+        if (!rc && stop)
+          HIP_TRY (hipEventRecord (stop, st));
+      }
     }
     if (rc) {
       /* earlier segments may have left a partial running total and expand ticket behind */

@@ -285,6 +285,8 @@ def _checksums(torch, rec, n):
 
 
 def _scan_whole_vs_shards(torch, plan, text, n, lmax, cap, shards=4):
+    """whole scan against the union of `shards` shard scans cut by the product's own
+    sharded.shard_bounds (what every rank of a multi-GPU job calls)"""
     rec = torch.empty((cap, 2), dtype=torch.int64, device="cuda")
     cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
     plan.scan(text, n, records=rec, count=cnt)
@@ -293,10 +295,8 @@ def _scan_whole_vs_shards(torch, plan, text, n, lmax, cap, shards=4):
     whole = _checksums(torch, rec, whole_n)
     assert int(plan.count(text, n).item()) == whole_n
     tot, sums = 0, [0, 0, 0, 0]
-    esz = text.element_size()
     for r in range(shards):
-        b, e = n * r // shards, n * (r + 1) // shards
-        rb = max(b - (lmax - 1), 0)
+        rb, b, e = acm.sharded.shard_bounds(n, r, shards, lmax)
         plan.scan(text[rb:e], e - rb, emit_from=b - rb, pos_base=rb, records=rec, count=cnt)
         k = int(cnt.item())
         c = _checksums(torch, rec, k)
@@ -309,6 +309,92 @@ def _scan_whole_vs_shards(torch, plan, text, n, lmax, cap, shards=4):
         return (v + (1 << 63)) % (1 << 64) - (1 << 63)
     assert tuple(wrap(v) for v in sums) == tuple(wrap(v) for v in whole)
     return whole_n
+
+
+def test_config4_sharded_eight_ranks_one_process(torch_cuda):
+    """BASELINE config 4's path on one GPU: config 4's dictionary (100k keywords), its text reduced
+    to 256 MiB, cut for R = 8 ranks by sharded.shard_bounds; every shard goes through the HIP scan
+    with its lmax-1 warm-up (emit_from, pos_base) and canonical sort, the per-rank record sets are
+    concatenated in rank order -- no global sort, exactly what gather_records does with them --
+    and the result must be the oracle's record set of the whole text (count + digest), in
+    canonical order.  One process, no collective."""
+    torch = torch_cuda
+    R, n = 8, 1 << 28
+    kd, ko = acm.synth.keywords(100000)
+    m, o = build_pair_packed(kd, ko, variant=po.MEYER85)
+    plan = m.plan(0)
+    assert plan.info.kernel == 5
+    text = acm.synth.device_text(n, kd, ko)
+    parts = []
+    for r in range(R):
+        rb, b, e = acm.sharded.shard_bounds(n, r, R, m.lmax)
+        assert rb == max(b - (m.lmax - 1), 0)
+        part = plan.scan_sorted(text[rb:e], emit_from=b - rb, pos_base=rb)
+        assert part.size and int(part["end_pos"].min()) >= b and int(part["end_pos"].max()) < e
+        parts.append(part)
+    cat = np.concatenate(parts)
+    host = text.cpu().numpy()
+    want_n, want_digest = o.scan_mt(host, max(1, len(os.sched_getaffinity(0))))
+    assert cat.size == want_n and po.digest(cat) == want_digest
+    key = cat["end_pos"].astype(np.int64) * 64 + (63 - cat["length"].astype(np.int64))
+    assert np.all(np.diff(key) > 0), "rank-order concatenation is not the canonical order"
+    # record for record on the seam between ranks 3 and 4
+    rb, b, e = acm.sharded.shard_bounds(n, 4, R, m.lmax)
+    lo, hi = b - (1 << 20), b + (1 << 20)
+    seam = o.scan(host[lo - 64:hi], pos_base=lo - 64, emit_from=64)
+    assert np.array_equal(cat[(cat["end_pos"] >= lo) & (cat["end_pos"] < hi)], seam)
+
+
+def _gloo_gpu_worker(rank, world, port, n, K, out_path):
+    """rank of a world-2 job whose ranks share cuda:0 (a one-GPU box): product sharding, product
+    HIP scan, product gather (gloo moves the records through host memory)."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    kd, ko = acm.synth.keywords(K)
+    m = acm.Machine(1)
+    m.add_keywords_packed(kd, ko)
+    plan = m.plan(0)
+
+    def make_shard(read_begin, own_end):
+        gb = read_begin // 4096 * 4096
+        return acm.synth.device_text(own_end - gb, kd, ko, begin=gb)[read_begin - gb:]
+
+    def scan_fn(text, emit_from, pos_base):
+        rec = plan.scan_sorted(text, emit_from=emit_from, pos_base=pos_base)
+        return torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.int64).reshape(-1, 2).copy()).cuda()
+
+    got = acm.sharded.scan_sharded(scan_fn, n, m.lmax, make_shard)
+    if rank == 0:
+        np.save(out_path, got.cpu().numpy())
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_scan_two_ranks_gloo_real_hip_scan(torch_cuda, tmp_path):
+    """sharded.scan_sharded end to end with the product kernel as each rank's scanner: two
+    processes on this one GPU over gloo (RCCL wants one GPU per rank; the N-GPU run is the
+    driver's), records gathered to rank 0 equal the oracle's scan of the whole text."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n, K = (24 << 20) + 4096 * 3 + 1234, 1000        # ragged: not a multiple of the block or the world size
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_gloo_gpu_worker, args=(2, port, n, K, out), nprocs=2, join=True)
+    got = np.frombuffer(np.load(out).tobytes(), dtype=acm.RECORD_DTYPE)
+    kd, ko = acm.synth.keywords(K)
+    o = po.Oracle(1)
+    o.add_keywords_packed(kd, ko)
+    want = o.scan(acm.synth.text((n + 4095) // 4096 * 4096, kd, ko)[:n])
+    assert np.array_equal(got, want)
 
 
 def test_config3_full_size_properties(torch_cuda):
@@ -382,6 +468,30 @@ def test_streaming_synthetic_large_pieces(torch_cuda):
     assert got.size == 35453 and po.digest(got) == 0x75c631ca92f2fd08
     assert np.all(np.diff(got["end_pos"].astype(np.int64)) >= 0)
     st.close()
+
+
+def test_streaming_pinned_buffers_reused_as_early_as_allowed(torch_cuda):
+    """The feed contract (acm_gpu.h): a host buffer may be overwritten once the SECOND next feed
+    has returned.  Three pinned buffers in rotation, each refilled right after that feed -- with
+    pinned memory the copies are truly asynchronous, so a missing host-side wait would let piece
+    k + 3 overwrite piece k before it has been copied."""
+    torch = torch_cuda
+    kd, ko = acm.synth.keywords(1000)
+    m, o = build_pair_packed(kd, ko)
+    piece, pieces = 4 << 20, 12
+    host = acm.synth.text(piece * pieces, kd, ko)
+    want = o.scan_mt(host, 8)
+    plan = m.plan(0)
+    st = plan.stream(max_piece_symbols=piece, record_capacity=1 << 16)
+    ring = [torch.empty(piece, dtype=torch.uint8).pin_memory() for _ in range(3)]
+    for k in range(pieces):
+        buf = ring[k % 3]                 # last used by feed k - 3; feeds k - 2 and k - 1 have returned
+        buf.numpy()[:] = host[k * piece:(k + 1) * piece]
+        st.feed_ptr(buf.data_ptr(), piece)
+    got = st.finish()
+    st.close()
+    assert (got.size, po.digest(got)) == want
+    assert np.array_equal(got[:1000], o.scan(host[:1 << 20])[:1000])
 
 
 @pytest.mark.parametrize("name", ["ternary_dense", "u16_symbols"])
