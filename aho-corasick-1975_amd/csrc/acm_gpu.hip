@@ -15,6 +15,9 @@
  *                                     mode with rows in HBM for bigger dictionaries
  *   dev_gram.h    scan_gram_kernel    byte alphabets, big dictionaries of keywords >= 4 symbols:
  *                                     4-gram bit table in LDS, every position tested on its own
+ *   dev_sieve.h   scan_sieve_kernel   byte alphabets, small dictionaries of keywords >= 4 symbols
+ *                                     (config 2: the headline kernel): trigram bits once per LDS
+ *                                     bank, one conflict-free ds_read_b32 per symbol
  *   dev_starts.h  scan_starts_kernel  2- and 4-byte symbols: root table by symbol value in LDS,
  *                                     every position tested on its own; walk_starts, hit parking
  *   dev_sparse.h  scan_sparse_kernel  2- and 4-byte symbols, automaton walk (ACM_GPU_SPARSE=walk)
@@ -68,6 +71,8 @@ constexpr int DENSE_THREADS = 1024; /* one workgroup per CU, 16 waves */
 #ifndef ACM_DENSE_S
 #define ACM_DENSE_S 2
 #endif
+/* a region must hold the items of two 16-step blocks beside a queue's worth: region_make_room */
+constexpr uint32_t DENSE_MIN_REGION_ITEMS = 2 * (16 * ACM_DENSE_S * WAVE + QCAP);
 constexpr uint64_t SEGMENT = 1ull << 31; /* symbols per launch: positions inside a launch are 32-bit */
 /* tests shrink it with ACM_GPU_SEGMENT_LOG2 to cross segment seams on small inputs */
 
@@ -130,6 +135,7 @@ constexpr uint32_t IT_OUT = 1u << 29;   /* report the outputs of the state itsel
 #include "dev_sparse.h"
 #include "dev_starts.h"
 #include "dev_gram.h"
+#include "dev_sieve.h"
 #include "dev_misc.h"
 
 } // namespace
@@ -186,6 +192,9 @@ struct ACMPlan {
   StartsMirror *mir = nullptr; /* starts plans: what acm_gpu_plan_update edits */
   GramK GK{};
   bool gram = false; /* 4-gram sieve kernel instead of the sticky dense walk */
+  SieveK VK{};
+  bool sieve = false; /* trigram sieve kernel in front of the 4-gram kernel's later stages */
+  uint32_t sieve_lds_bytes = 0;
   bool gram_shorts = false, gram_wide = false;
   uint32_t gram_lds_bytes = 0;
   uint32_t class_sym_bytes = 0; /* comparator-class plans: the symbol size they were made for */
@@ -219,8 +228,8 @@ struct ACMPlan {
   uint64_t generation = 0; /* for the machine-cached plan */
   /* ACM_GPU_EXPAND (experiments): 2 = expand_items_once_kernel, one atomic per block (default:
    * config 2 step 0.3202 -> 0.3182 ms); 0 = expand_items_kernel, one atomic per round of 1024
-   * items; 1 = no parking, every wave expands its own queue inside the scan kernel (measured
-   * 0.277 -> 0.427 ms on the scan kernel: the walks stall the wave) */
+   * items.  (Tried: no parking at all, every wave expanding its own queue inside the scan kernel:
+   * 0.277 -> 0.427 ms on the scan kernel, the walks stall the wave.) */
   int expand_mode = 2;
   int cu_count = 0;
   /* timing */
@@ -421,6 +430,7 @@ struct GramImage {
   uint32_t W, bloom_log2, wtab_log2, stab_log2;
   uint32_t *bits, *g4, *rec, *edge, *g4gid; /* first-stage bits, second-stage records, trie records (depth-first), their edges, depth-4 state -> record */
   unsigned char *nib;                      /* narrow alphabets: nibble per 3-gram */
+  uint32_t *tri;                           /* trigram sieve kernel: [W * W] words, bit c2 of word c0 * W + c1 (NULL: not wanted) */
   uint32_t *g3, *stab;                     /* short keywords: prefix states per 3-gram (narrow) / table of tagged windows (wide) */
 };
 
@@ -471,6 +481,8 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
       path[fv.edge_next[e]] = G.wide ? path[st] | (fv.edge_sym[e] << (8 * fv.depth[st])) /* the 4 bytes as the text holds them */
                                         : path[st] * G.W + (fv.edge_sym[e] - fi.alpha_lo);
+  for (uint32_t st = fv.depth_start[3]; G.tri && st < fv.depth_start[4]; st++)
+    G.tri[path[st] / G.W] |= 1u << (path[st] % G.W);
   for (uint32_t st = fv.depth_start[4]; G.wide && st < fv.depth_start[5]; st++) {
     const uint32_t win = path[st];
     const uint32_t hb = (win * WIDE_H1) >> (32 - G.bloom_log2);
@@ -648,12 +660,24 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     for (uint32_t s = HD; s < n; s++)
       rowless_share += pow ((double)fi.alpha_span, -(double)fv.depth[s]);
   }
-  const bool gram_big = dense && (entry_bytes == 4 || gram_mode >= 2 || rowless_share > 0.001) && gram_mode != 0 && fi.lmax >= 4 &&
-                        n < 0x40000000u;
   const bool gram_narrow = fi.width <= 30 && fi.width == fi.alpha_span + 1 && gram_mode != 3; /* 3: hashed windows always (experiments) */
-  bool gram_shorts = false; /* keywords of 1-3 symbols: the kernel's nibble table and third queue */
-  for (uint32_t k = 0; k < fi.n_keywords && gram_big; k++)
-    gram_shorts |= fv.depth[fv.kw_state[k]] < 4;
+  /* trigram sieve kernel (dev_sieve.h): narrow alphabets, every keyword of 4 symbols or more, and
+   * a trigram set thin enough to be a sieve (config 2: 5 % of the W^3 trigrams; above 12 % the
+   * candidates would swamp its second stage).  Only with ACM_GPU_SIEVE=1: measured SLOWER than the
+   * dense kernel on config 2 (0.63 against 0.28 ms per GiB; its first stage alone, candidates only
+   * counted, takes the dense kernel's 0.28 ms: both are bound by VALU issue -- a wave64 integer
+   * instruction holds its SIMD for 4 cycles, and either kernel needs ~6 of them per symbol -- not
+   * by the LDS lookups the sieve makes conflict-free). */
+  bool any_short = false;
+  for (uint32_t k = 0; k < fi.n_keywords; k++)
+    any_short |= fv.depth[fv.kw_state[k]] < 4;
+  const char *sieve_env = getenv ("ACM_GPU_SIEVE");
+  const bool sieve_want = dense && gram_narrow && gram_mode != 0 && sieve_env && atoi (sieve_env) == 1 && fi.lmax >= 4 && !any_short &&
+                          n < 0x40000000u && fi.n_keywords > 0 &&
+                          (double)(fv.depth_start[4] - fv.depth_start[3]) <= 0.12 * (double)fi.width * fi.width * fi.width;
+  const bool gram_big = dense && (entry_bytes == 4 || gram_mode >= 2 || rowless_share > 0.001 || sieve_want) && gram_mode != 0 &&
+                        fi.lmax >= 4 && n < 0x40000000u;
+  bool gram_shorts = gram_big && any_short; /* keywords of 1-3 symbols: the kernel's nibble table and third queue */
   /* wide alphabets: hashed 4-byte windows instead of the exact base-W index */
   const bool gram_wide = gram_big && !gram_narrow;
   bool gram = gram_big;
@@ -686,6 +710,8 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const size_t o_grec = blob_reserve (cur, gram ? (size_t)n * 32 : 0);
   const size_t o_gedge = blob_reserve (cur, gram ? (size_t)fi.n_edges * 8 : 0);
   const size_t o_g4gid = blob_reserve (cur, gram ? (size_t)(fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1] - fv.depth_start[4]) * 4 + 16 : 0);
+  const bool sieve = gram && sieve_want;
+  const size_t o_tri = blob_reserve (cur, sieve ? (size_t)gW * gW * 4 + 16 : 0);
   p->blob_bytes = cur;
 
   std::vector<unsigned char> host (cur, 0);
@@ -728,6 +754,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     G.nib = &host[o_g4bits + g3_off];
     G.g3 = reinterpret_cast<uint32_t *> (&host[o_g3rec]);
     G.stab = reinterpret_cast<uint32_t *> (&host[o_stab]);
+    G.tri = sieve ? reinterpret_cast<uint32_t *> (&host[o_tri]) : nullptr;
     fill_gram_tables (fv, fi, G);
   }
   if (dense) {
@@ -826,6 +853,16 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       p->GK.queue_off = bits_bytes;
       p->gram_lds_bytes = bits_bytes + gq + WALK_CTX_BYTES;
     }
+    const uint32_t tri_bytes = gW * gW * 128u; /* every word once per bank of a lane group */
+    const uint32_t sq = (SPARSE_THREADS / WAVE) * (2 * QCAP + HITS_STRIDE) * 8;
+    if (p->gram && sieve && (uint64_t)tri_bytes + sq + WALK_CTX_BYTES <= lds_total) {
+      p->sieve = true;
+      p->VK.G = p->GK;
+      p->VK.G.queue_off = tri_bytes;
+      p->VK.tri = u32p (o_tri);
+      p->VK.tri_words = gW * gW;
+      p->sieve_lds_bytes = tri_bytes + sq + WALK_CTX_BYTES;
+    }
   }
   if (sparse) {
     const uint32_t tps = 128 / fi.sym_bytes;
@@ -896,7 +933,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
 
   ACMPlanInfo &I = p->info;
   I.device = device;
-  I.kernel = p->gram ? 5 : (dense ? 1 : (sparse ? (p->starts ? 4 : 3) : 2));
+  I.kernel = p->sieve ? 6 : (p->gram ? 5 : (dense ? 1 : (sparse ? (p->starts ? 4 : 3) : 2)));
   I.entry_bytes = dense ? entry_bytes : 0;
   I.width = fi.width;
   I.dense_rows = dense ? n : 0;
@@ -920,6 +957,13 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       return ACM_GPU_E_HIP;                                                                        \
     }                                                                                              \
   } while (0)
+  if (p->gram) {
+    I.lds_bytes = p->sieve ? p->sieve_lds_bytes : p->gram_lds_bytes;
+    I.block_threads = SPARSE_THREADS;
+    I.grid_blocks = (uint32_t)p->cu_count;
+    I.streams = 1;
+    I.chunk_bytes = 16;
+  }
   if (sparse) {
     I.lds_bytes = p->starts ? p->starts_lds_bytes : p->sparse_lds_bytes;
     I.block_threads = SPARSE_THREADS;
@@ -934,12 +978,18 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->starts_lds_bytes));
     }
   }
+  if (p->sieve) {
+    PLAN_TRY (hipFuncSetAttribute (reinterpret_cast<const void *> (&scan_sieve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)p->sieve_lds_bytes));
+    PLAN_TRY (hipFuncSetAttribute (reinterpret_cast<const void *> (&scan_sieve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)p->sieve_lds_bytes));
+  }
   if (p->gram) {
     for (int co = 0; co < 2; co++)
       PLAN_TRY (hipFuncSetAttribute (gram_kernel_ptr (co != 0, p->gram_shorts, p->gram_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)p->gram_lds_bytes));
   }
-  if (dense) {
+  if (dense && !p->gram) {
     for (int co = 0; co < 2; co++)
       PLAN_TRY (hipFuncSetAttribute (dense_kernel_ptr (entry_bytes, p->chunk, p->streams, co != 0),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)I.lds_bytes));
@@ -1234,9 +1284,17 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t 
   set_tile_pool (p, a, grid * wpb);
   void *items = COUNT_ONLY ? nullptr : p->d_items;
   uint32_t *fill = COUNT_ONLY ? nullptr : p->d_fill;
-  void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
-  HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts, p->gram_wide), dim3 (grid), dim3 (SPARSE_THREADS), args,
-                            p->gram_lds_bytes, st));
+  if (p->sieve) {
+    SieveK V = p->VK;
+    V.G.R = (uint32_t)R;
+    void *vargs[] = { &V, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
+    HIP_TRY (hipLaunchKernel (reinterpret_cast<const void *> (&scan_sieve_kernel<COUNT_ONLY>), dim3 (grid), dim3 (SPARSE_THREADS), vargs,
+                              p->sieve_lds_bytes, st));
+  } else {
+    void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
+    HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts, p->gram_wide), dim3 (grid), dim3 (SPARSE_THREADS), args,
+                              p->gram_lds_bytes, st));
+  }
   if (stop)
     HIP_TRY (hipEventRecord (stop, st));
   if (!COUNT_ONLY)
@@ -1276,12 +1334,12 @@ launch_csr (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
 /* (re)allocate the item buffer for segments of up to n symbols: room for one item per 256
  * symbols, at least 256 per wave; denser matches are expanded in the kernel itself */
 int
-ensure_item_buffer (ACMPlan *p, uint64_t n, uint32_t symbols_per_item = 256) {
+ensure_item_buffer (ACMPlan *p, uint64_t n, uint32_t symbols_per_item = 256, uint32_t min_items = 256) {
   const uint32_t regions = p->info.grid_blocks * (DENSE_THREADS / WAVE);
   uint64_t per = (n / symbols_per_item + regions - 1) / regions;
   per = (per + 63) / 64 * 64;
-  if (per < 256)
-    per = 256;
+  if (per < min_items)
+    per = min_items;
   if (per > (1u << 20))
     per = 1u << 20;
   if (p->d_items && p->regions == regions && p->region_items >= per)
@@ -1317,10 +1375,6 @@ launch_expand (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, const Expand
 template <bool CONT, bool COUNT_ONLY>
 void
 launch_expand_cfg (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, const ExpandTail &tail, hipStream_t st) {
-  if (p->expand_mode == 1) { /* nothing was parked: one block hands the total over */
-    launch_expand<CONT, COUNT_ONLY, 1024, 16> (p, E, 16, tail, st);
-    return;
-  }
   if (p->expand_mode == 2) {
     const dim3 g ((regions_used + 15) / 16);
     hipLaunchKernelGGL ((expand_items_once_kernel<CONT, COUNT_ONLY, 1024, 16, 4>), g, dim3 (1024), 0, st, E,
@@ -1353,9 +1407,8 @@ launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
   a.pool_ctr = p->d_pool_ctr + (p->launch_seq & 1) * POOL_CLASSES * POOL_CTR_STRIDE;
   a.pool_reset = p->d_pool_ctr + ((p->launch_seq & 1) ^ 1) * POOL_CLASSES * POOL_CTR_STRIDE;
   p->launch_seq++;
-  void *no_items = nullptr;
   void *args[] = { &p->K, const_cast<EmitCtx *> (&E), &a, &p->d_dense, &p->d_lds_image, &p->lds_image_bytes, &a.text,
-                   p->expand_mode == 1 ? &no_items : &p->d_items, &p->region_items, &p->d_fill, &p->d_dstart };
+                   &p->d_items, &p->region_items, &p->d_fill, &p->d_dstart };
   HIP_TRY (hipLaunchKernel (dense_kernel_ptr (p->entry_bytes, p->chunk, p->streams, COUNT_ONLY), dim3 (grid), dim3 (DENSE_THREADS), args,
                             p->info.lds_bytes, st));
   if (stop)
@@ -1683,7 +1736,7 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   }
   if (use_dense || (!COUNT_ONLY && (p->gram || p->starts))) {
     /* 4-gram plans see dense matches (config 3: one per 38 symbols): room for one hit per 16 */
-    int rc = ensure_item_buffer (p, n < p->segment ? n : p->segment, p->gram ? 16 : 256);
+    int rc = ensure_item_buffer (p, n < p->segment ? n : p->segment, p->gram && !p->sieve ? 16 : 256, use_dense ? DENSE_MIN_REGION_ITEMS : 256);
     if (rc)
       return rc;
   }

@@ -58,7 +58,7 @@ dense_step_slow (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t
   constexpr uint32_t IDMASK = FLAG - 1;
   constexpr bool CONT = EntryTraits<ENTRY>::CONT;
   bool rowless = false;
-  uint32_t ns[S], carry[S];
+  uint32_t ns[S], hf[S];
   /* first all the loads, so that their latencies overlap with the queue bookkeeping below */
 #pragma unroll
   for (int q = 0; q < S; q++) {
@@ -68,9 +68,9 @@ dense_step_slow (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t
 #pragma unroll
   for (int q = 0; q < S; q++) {
     ns[q] = e[q] & IDMASK;
-    carry[q] = ns[q];
+    hf[q] = 0;
     if (CONT && ns[q] >= K.HD) /* the lane carries on from the nearest state that has a row */
-      carry[q] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint16_t *> (K.aux_off + (ns[q] - K.HD) * 2u);
+      hf[q] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint16_t *> (K.aux_off + (ns[q] - K.HD) * 2u);
   }
 #pragma unroll
   for (int q = 0; q < S; q++) {
@@ -84,14 +84,18 @@ dense_step_slow (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t
       uint32_t word = ns[q] | (deep ? IT_CONT : 0u) | (out ? IT_OUT : 0u);
       if (at.phase == PH_RUN)
         word |= IT_RUN | (at.k << IT_K_SHIFT);
-      queue_push<CONT, COUNT_ONLY> (E, queue, w.qn, out | deep, pos, word, lane, &w.spill);
+      queue_push<CONT, COUNT_ONLY, true> (E, queue, w.qn, out | deep, pos, word, lane, &w.spill);
     } else {
       const bool out = at.phase == PH_MAIN && (e[q] & FLAG) && window;
-      queue_push<CONT, COUNT_ONLY> (E, queue, w.qn, out, pos, ns[q], lane, &w.spill);
+      queue_push<CONT, COUNT_ONLY, true> (E, queue, w.qn, out, pos, ns[q], lane, &w.spill);
       rowless |= ns[q] >= K.HD;
     }
-    w.s[q] = carry[q];
   }
+  /* the next states go into e[] itself, after its last use above: the caller takes them from
+   * there on both sides of its branch, so the looked-up entry and the state can share a register */
+#pragma unroll
+  for (int q = 0; q < S; q++)
+    e[q] = (CONT && ns[q] >= K.HD) ? hf[q] : ns[q];
   if (!CONT)
     w.sticky = rowless ? ~0u : 0u;
 }
@@ -117,11 +121,12 @@ dense_step (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emit
     DIAG (const unsigned long long t0_ = __builtin_readcyclecounter ();)
     dense_step_slow<ENTRY, S, COUNT_ONLY> (K, E, emit_from, emit_end, gdense, queue, w, e, cls, at, lane);
     DIAG (w.d_slow_cycles += __builtin_readcyclecounter () - t0_; w.d_slow_steps++;)
-  } else {
-#pragma unroll
-    for (int q = 0; q < S; q++)
-      w.s[q] = e[q];
   }
+  /* (one assignment for both sides: with `w.s = e` on the fast side only, the register allocator
+   * kept the looked-up entries and the states apart and paid two v_mov per step for it) */
+#pragma unroll
+  for (int q = 0; q < S; q++)
+    w.s[q] = e[q];
 }
 
 /* 16 steps over one 16-byte block per stream; at = where the block's first byte is */
@@ -129,6 +134,7 @@ template <typename ENTRY, int S, bool COUNT_ONLY>
 __device__ __forceinline__ void
 dense_block (const DenseK &K, const EmitCtx &E, uint32_t emit_from, uint32_t emit_end, const ENTRY *__restrict__ gdense,
              uint2 *queue, Walk<S> &w, const uint4 (&blk)[S], const StepAt at, uint32_t lane) {
+  region_make_room<EntryTraits<ENTRY>::CONT, COUNT_ONLY, S> (E, &w.spill);
 #define ACM_BYTE(COMP, SH, J)                                                                      \
   {                                                                                                \
     uint32_t b_[S];                                                                                \
@@ -232,7 +238,7 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
   w.qn = 0;
   w.sticky = 0;
   w.spill.region = items + (size_t)wave * region_items;
-  w.spill.capacity = items ? region_items : 0;
+  w.spill.capacity = region_items; /* >= DENSE_MIN_REGION_ITEMS: ensure_item_buffer */
   w.spill.fill = 0;
   DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); const unsigned long long d_w0 = wall_clock64 (); unsigned long long d_text = 0, d_tiles = 0;)
 
@@ -322,6 +328,7 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
           for (int q = 0; q < S; q++)
             post[q] = load_block (pos0, NB + b, q);
         }
+        region_make_room<CONT, COUNT_ONLY, S> (E, &w.spill);
 #define ACM_RUN_BYTE(COMP, SH, J)                                                                  \
   if (!done) {                                                                                     \
     const uint32_t k_ = 16 * b + (J) + 1;                                                          \
@@ -345,8 +352,8 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
         post[q] = load_block (npos0, NB, q);
     }
   }
-  if (w.qn)
-    queue_drain<CONT, COUNT_ONLY> (E, queue, w.qn, &w.spill, lane);
+  if (w.qn) /* (at most 64 items: the last block's room covers them) */
+    queue_drain<CONT, COUNT_ONLY, true> (E, queue, w.qn, &w.spill, lane);
   if (lane == 0 && fill)
     fill[wave] = w.spill.fill;
   DIAG (if (lane == 0 && wave < 8192) {

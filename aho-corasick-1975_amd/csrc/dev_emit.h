@@ -181,10 +181,12 @@ struct Spill {
   uint32_t fill;     /* items parked so far (wave-uniform) */
 };
 
-template <bool CONT, bool COUNT_ONLY>
+template <bool CONT, bool COUNT_ONLY, bool PARK_ONLY = false>
 __device__ __forceinline__ void
 queue_drain (const EmitCtx &E, const uint2 *queue, uint32_t qn, Spill *sp, uint32_t lane) {
-  if (sp && sp->fill + qn <= sp->capacity) {
+  /* PARK_ONLY (dense kernel): the caller has made room in the region (region_make_room), so there
+   * is no call to flush_queue on this path -- it runs at every slow step of 128 unrolled ones */
+  if (PARK_ONLY || (sp && sp->fill + qn <= sp->capacity)) {
     for (uint32_t i = lane; i < qn; i += WAVE)
       sp->region[sp->fill + i] = queue[i];
     sp->fill = uniform (sp->fill + qn);
@@ -193,7 +195,7 @@ queue_drain (const EmitCtx &E, const uint2 *queue, uint32_t qn, Spill *sp, uint3
 }
 
 /* append one item per lane with `hit`; wave-uniform bookkeeping in qn */
-template <bool CONT, bool COUNT_ONLY>
+template <bool CONT, bool COUNT_ONLY, bool PARK_ONLY = false>
 __device__ __forceinline__ void
 queue_push (const EmitCtx &E, uint2 *queue, uint32_t &qn, bool hit, uint32_t pos, uint32_t word, uint32_t lane,
             Spill *sp = nullptr) {
@@ -203,9 +205,22 @@ queue_push (const EmitCtx &E, uint2 *queue, uint32_t &qn, bool hit, uint32_t pos
       queue[qn + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos, word);
     qn = uniform (qn + (uint32_t)__popcll (m));
     if (qn > QCAP - WAVE) {
-      queue_drain<CONT, COUNT_ONLY> (E, queue, qn, sp, lane);
+      queue_drain<CONT, COUNT_ONLY, PARK_ONLY> (E, queue, qn, sp, lane);
       qn = 0;
     }
+  }
+}
+
+/* Dense kernel, before every 16-step block: the block parks at most 16 * S * 64 items (one per
+ * lane, stream and step) beside what the queue already holds; a region that cannot take that much
+ * any more is expanded in place (records straight from here, one atomic per 64 items) and starts
+ * over.  Regions are sized so that this happens only on texts with a match every few symbols. */
+template <bool CONT, bool COUNT_ONLY, int S>
+__device__ __forceinline__ void
+region_make_room (const EmitCtx &E, Spill *sp) {
+  if (sp->capacity - sp->fill < 16u * S * WAVE + QCAP) {
+    flush_queue<CONT, COUNT_ONLY> (E, sp->region, sp->fill);
+    sp->fill = 0;
   }
 }
 

@@ -40,7 +40,7 @@ CONFIGS = {
     4: dict(keywords=100000, sym=1, mib=16384, cpu_mib=16, idx=3),
     5: dict(keywords=10000, sym=4, mib=4096, cpu_mib=64, idx=4),
 }
-KERNELS = {1: "scan_dense_kernel", 2: "scan_csr_kernel", 3: "scan_sparse_kernel", 4: "scan_starts_kernel", 5: "scan_gram_kernel"}
+KERNELS = {1: "scan_dense_kernel", 2: "scan_csr_kernel", 3: "scan_sparse_kernel", 4: "scan_starts_kernel", 5: "scan_gram_kernel", 6: "scan_sieve_kernel"}
 VOCAB = 32768
 # known answer of config 2 at full size (1 GiB, rank 0): oracle, AC-75 variant, whole text
 CONFIG2_FULL = (555000, 0xdc822ef7f043a221)

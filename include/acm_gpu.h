@@ -145,7 +145,11 @@ typedef struct {
                             3 = sparse automaton walk when the environment says ACM_GPU_SPARSE=walk;
                             5 = 4-gram sieve kernel: byte dictionaries whose hot rows outgrow LDS (more than about
                             1,300 keywords over a-z) with some keyword of 4 symbols or more
-                            (ACM_GPU_GRAM=0: kernel 1 instead, ACM_GPU_GRAM=2: kernel 5 whenever possible) */
+                            (ACM_GPU_GRAM=0: kernel 1 instead, ACM_GPU_GRAM=2: kernel 5 whenever possible);
+                            6 = trigram sieve kernel, only when the environment says ACM_GPU_SIEVE=1 (an experiment kept
+                            for the record: slower than kernel 1): byte dictionaries over at most 29 distinct symbols whose
+                            keywords all have 4 symbols or more and start with few different trigrams; trigram bits once per
+                            LDS bank, conflict-free, then kernel 5's later stages */
   uint32_t entry_bytes;  /* dense entries: 2 or 4 */
   uint32_t width;        /* dense row width */
   uint32_t dense_rows;   /* rows resident in HBM */

@@ -708,6 +708,18 @@ def _random_case(rng, kind):
         kws.append(rng.integers(lo, lo + span, size=top).astype(np.uint8))      # at least one keyword of 4 symbols or more
         text = rng.integers(max(lo - 1, 0), min(lo + span + 1, 256), size=int(rng.integers(1, 200000))).astype(np.uint8)
         return kws, text, 1, {"ACM_GPU_GRAM": "2"}
+    if kind == "sieve":             # narrow alphabet, keywords of 4 symbols or more, thin trigram set: trigram sieve kernel
+        lo = int(rng.integers(0, 220)); span = int(rng.integers(16, 29))
+        kws = [rng.integers(lo, lo + span, size=rng.integers(4, 13)).astype(np.uint8) for _ in range(int(rng.integers(1, 400)))]
+        text = rng.integers(max(lo - 1, 0), min(lo + span + 1, 256), size=int(rng.integers(1, 300000))).astype(np.uint8)
+        # dense candidates: re-use keyword heads of 3 to 6 symbols so that every stage sees rejects
+        for _ in range(min(3000, text.size // 16)):
+            w = kws[int(rng.integers(0, len(kws)))]
+            k = min(w.size, 3 + int(rng.integers(0, 4)))
+            at = int(rng.integers(0, max(text.size - 12, 1)))
+            if at + k <= text.size:
+                text[at:at + k] = w[:k]
+        return kws, text, 1, {"ACM_GPU_SIEVE": "1"}
     if kind in ("wide", "wideshort"):   # more than 29 symbols in use, > 32768 states: hashed 4-byte windows (and shorter ones)
         lo = int(rng.integers(0, 120)); span = int(rng.integers(31, 136))
         if rng.integers(0, 3) == 0:
@@ -733,7 +745,7 @@ def _random_case(rng, kind):
     return kws, text, sym, ({"ACM_GPU_SPARSE": "walk"} if kind.startswith("walk") else {})
 
 
-@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "gram", "gramsmall", "wide", "wideshort", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
+@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "sieve", "gram", "gramsmall", "wide", "wideshort", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
                                        for s in range(int(os.environ.get("ACM_SOAK_SEEDS", "3")))])   # ACM_SOAK_SEEDS=14: a soak run
 def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed):
     """Random dictionaries and texts through every kernel family; whole scans, count-only scans and
@@ -752,11 +764,11 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
             text[at:at + w.size] = w
     m, o = build_pair(kws, sym)
     plan = m.plan(0)
-    expect = {"dense": 1, "gram": 5, "gramsmall": 5, "wide": 5, "wideshort": 5, "sticky": 1, "short": 5, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
+    expect = {"dense": 1, "sieve": 6, "gram": 5, "gramsmall": 5, "wide": 5, "wideshort": 5, "sticky": 1, "short": 5, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
     if kind in ("gram", "wide", "wideshort", "sticky", "short"):
         assert plan.info.dense_rows > 32768, "the generator is meant to give more states than the LDS scheme takes"
     if kind == "dense":     # small dictionaries whose hot rows outgrow LDS go to the 4-gram kernel by themselves
-        assert plan.info.kernel in (1, 5), plan.info.kernel
+        assert plan.info.kernel in (1, 5, 6), plan.info.kernel
     else:
         assert plan.info.kernel == expect, (kind, plan.info.kernel)
     want = o.scan(text)
