@@ -229,7 +229,10 @@ struct ACMPlan {
   /* ACM_GPU_EXPAND (experiments): 2 = expand_items_once_kernel, one atomic per block (default:
    * config 2 step 0.3202 -> 0.3182 ms); 0 = expand_items_kernel, one atomic per round of 1024
    * items.  (Tried: no parking at all, every wave expanding its own queue inside the scan kernel:
-   * 0.277 -> 0.427 ms on the scan kernel, the walks stall the wave.) */
+   * 0.277 -> 0.427 ms on the scan kernel, the walks stall the wave; smaller blocks -- 512 x 8
+   * regions, 256 x 4, 256 x 2, with 2 or 4 rounds in registers -- 44 to 77 us against 39: every
+   * block costs two atomics on one line; warming the L2s with the continuation rows and output
+   * records at the start of the kernel: 1 us.) */
   int expand_mode = 2;
   int cu_count = 0;
   /* timing */
