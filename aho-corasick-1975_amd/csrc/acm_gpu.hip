@@ -99,7 +99,13 @@ struct EmitCtx {
   uint32_t chunk; /* bytes per lane-stream chunk of the dense kernel (a power of two) */
   uint32_t n_states;
   unsigned int *error; /* set to 1 if an item with an impossible state id is ever met (never expected) */
+  /* 4-gram kernels: keyword id of every depth-4 state by its rank among them (NONE: not a keyword).
+   * A hit whose state word carries HIT_LEN4 names such a state by that rank: its record is
+   * (position, 4, kw4[rank]) -- a 360 KB table that stays in L2 instead of the 16-byte output
+   * records of all 508,339 states (config 3: 26 of 27 M hits per GiB are keywords of 4 symbols) */
+  const uint32_t *kw4;
 };
+constexpr uint32_t HIT_LEN4 = 0x80000000u;
 
 /* one launch: a segment of the buffer, positions relative to its first symbol */
 struct Launch {
@@ -184,6 +190,7 @@ struct ACMPlan {
   /* CSR kernel (breadth-first numbering) */
   CsrTables csr{};
   const uint4 *d_oinfo = nullptr;
+  const uint32_t *d_kw4 = nullptr;
   const uint16_t *d_cont_dh = nullptr;
   /* sparse kernel (2- and 4-byte symbols) */
   SparseK SK{};
@@ -434,6 +441,8 @@ struct GramImage {
   uint32_t *bits, *g4, *rec, *edge, *g4gid; /* first-stage bits, second-stage records, trie records (depth-first), their edges, depth-4 state -> record */
   unsigned char *nib;                      /* narrow alphabets: nibble per 3-gram */
   uint32_t *tri;                           /* trigram sieve kernel: [W * W] words, bit c2 of word c0 * W + c1 (NULL: not wanted) */
+  uint32_t *bloom;                         /* narrow alphabets: Bloom bits, terminal 4-grams then 5-grams (GramK::bloom5_bits; NULL: none) */
+  uint32_t bloomT_bits, bloom5_bits, lo;
   uint32_t *g3, *stab;                     /* short keywords: prefix states per 3-gram (narrow) / table of tagged windows (wide) */
 };
 
@@ -504,6 +513,18 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     bits[idx >> 5] |= 1u << (idx & 31);
     g4[2 * (size_t)idx] = mask;
     g4[2 * (size_t)idx + 1] = st;
+    if (G.bloom) {
+      auto set = [&] (uint32_t slot) { G.bloom[slot >> 5] |= 1u << (slot & 31); };
+      if (fv.term_kw[st] != NONE) {
+        set (gram_bloom_slot (idx, G.bloomT_bits, 0));
+        set (gram_bloom_slot (idx, G.bloomT_bits, 1));
+      }
+      for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++) {
+        const uint32_t key5 = idx * G.W + (fv.edge_sym[e] - G.lo);
+        set (G.bloomT_bits + gram_bloom_slot (key5, G.bloom5_bits, 0));
+        set (G.bloomT_bits + gram_bloom_slot (key5, G.bloom5_bits, 1));
+      }
+    }
   }
   if (G.shorts && G.wide) {
     uint32_t *stab = G.stab;
@@ -706,13 +727,42 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const uint32_t gW3 = gram && !gram_wide ? gW * gW * gW : 0;
   const uint32_t g3_off = (g4words * 4 + 15) & ~15u;                 /* nibble table right after the 4-gram bits */
   const uint32_t g3_bytes = gram_shorts && !gram_wide ? ((gW3 + 1) / 2 + 15) & ~15u : 0;
-  const size_t o_g4bits = blob_reserve (cur, gram ? (size_t)g3_off + g3_bytes + 16 : 0);
+  /* narrow alphabets: what LDS has left after the bits and the queues goes to the two Bloom filters
+   * of the record gather (GramK::bloom5_bits): 8 to 16 bits per terminal 4-gram, the rest for the
+   * 5-grams; not worth it below 4 bits per 5-gram or for dictionaries of a few hundred keywords */
+  uint32_t bloom_off = 0, bloomT_bits = 0, bloom5_bits = 0;
+  if (gram && !gram_wide && n_depth4 >= 2048) {
+    const uint32_t lds_cap = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
+    const uint32_t gq_bytes = (SPARSE_THREADS / WAVE) * ((gram_shorts ? 3 : 2) * QCAP + HITS_STRIDE) * 8;
+    bloom_off = (g3_off + g3_bytes + 15) & ~15u;
+    const uint64_t used = (uint64_t)bloom_off + gq_bytes + WALK_CTX_BYTES + 64;
+    uint32_t n_term4 = 0, n_5 = 0;
+    for (uint32_t st = fv.depth_start[4]; st < fv.depth_start[5]; st++) {
+      n_term4 += fv.term_kw[st] != NONE ? 1u : 0u;
+      n_5 += fv.row_ptr[st + 1] - fv.row_ptr[st];
+    }
+    if (used < lds_cap) {
+      const uint64_t free_bits = ((uint64_t)lds_cap - used) / 16 * 16 * 8;
+      uint64_t tb = (uint64_t)n_term4 * 12 + 1024;
+      if (tb > free_bits / 3)
+        tb = free_bits / 3;
+      tb = tb / 128 * 128;
+      const uint64_t fb = (free_bits - tb) / 128 * 128;
+      if (tb >= 1024 && fb >= (uint64_t)n_5 * 3 && fb < (1u << 24)) {
+        bloomT_bits = (uint32_t)tb;
+        bloom5_bits = (uint32_t)fb;
+      }
+    }
+  }
+  const uint32_t bloom_bytes = bloom5_bits ? (bloomT_bits + bloom5_bits) / 8 : 0;
+  const size_t o_g4bits = blob_reserve (cur, gram ? (size_t)(bloom5_bits ? bloom_off + bloom_bytes : g3_off + g3_bytes) + 16 : 0);
   const size_t o_g3rec = blob_reserve (cur, gram_shorts && !gram_wide ? (size_t)gW3 * 16 : 0);
   const size_t o_stab = blob_reserve (cur, gram_wide && gram_shorts ? ((size_t)8 << stab_log2) : 0);
   const size_t o_g4rec = blob_reserve (cur, gram ? (size_t)gW4 * 8 : 0);
   const size_t o_grec = blob_reserve (cur, gram ? (size_t)n * 32 : 0);
   const size_t o_gedge = blob_reserve (cur, gram ? (size_t)fi.n_edges * 8 : 0);
   const size_t o_g4gid = blob_reserve (cur, gram ? (size_t)(fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1] - fv.depth_start[4]) * 4 + 16 : 0);
+  const size_t o_kw4 = blob_reserve (cur, gram ? (size_t)n_depth4 * 4 + 16 : 0);
   const bool sieve = gram && sieve_want;
   const size_t o_tri = blob_reserve (cur, sieve ? (size_t)gW * gW * 4 + 16 : 0);
   p->blob_bytes = cur;
@@ -757,7 +807,13 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     G.nib = &host[o_g4bits + g3_off];
     G.g3 = reinterpret_cast<uint32_t *> (&host[o_g3rec]);
     G.stab = reinterpret_cast<uint32_t *> (&host[o_stab]);
+    for (uint32_t st = fv.depth_start[4]; st < fv.depth_start[5]; st++)
+      reinterpret_cast<uint32_t *> (&host[o_kw4])[st - fv.depth_start[4]] = fv.term_kw[st];
     G.tri = sieve ? reinterpret_cast<uint32_t *> (&host[o_tri]) : nullptr;
+    G.bloom = bloom5_bits ? reinterpret_cast<uint32_t *> (&host[o_g4bits + bloom_off]) : nullptr;
+    G.bloomT_bits = bloomT_bits;
+    G.bloom5_bits = bloom5_bits;
+    G.lo = fi.alpha_lo;
     fill_gram_tables (fv, fi, G);
   }
   if (dense) {
@@ -828,8 +884,12 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   if (gram) {
     const uint32_t lds_total = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
     const uint32_t gq = (SPARSE_THREADS / WAVE) * ((gram_shorts ? 3 : 2) * QCAP + HITS_STRIDE) * 8;
-    const uint32_t bits_bytes = g3_off + g3_bytes;
+    const uint32_t bits_bytes = bloom5_bits ? bloom_off + bloom_bytes : g3_off + g3_bytes;
     if ((uint64_t)bits_bytes + gq + WALK_CTX_BYTES <= lds_total) {
+      p->d_kw4 = u32p (o_kw4);
+      p->GK.bloom_off = bloom_off;
+      p->GK.bloomT_bits = bloomT_bits;
+      p->GK.bloom5_bits = bloom5_bits;
       p->gram = true;
       p->GK.g4rec = reinterpret_cast<const uint2 *> (b + o_g4rec);
       p->GK.g4bits = u32p (o_g4bits);
@@ -1755,6 +1815,7 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   E.span = p->K.span;
   E.chunk = p->chunk;
   E.n_states = p->finfo.n_states;
+  E.kw4 = p->d_kw4;
   E.error = p->d_total ? reinterpret_cast<unsigned int *> (p->d_total) + 3 : nullptr;
 
   /* segments of at most SEGMENT symbols; each restarts from the root `halo` symbols early

@@ -47,11 +47,25 @@ struct GramK {
   const uint2 *stab;
   uint32_t stab_log2, short_lens;
   uint32_t W, lo, span, W4; /* class = min (byte - lo, span); W = span + 1 */
+  /* narrow alphabets: two Bloom filters in LDS behind the 4-gram bits, looked at when a batch of
+   * first-queue items sends for its records: "this 4-gram is a keyword" (key = the 4-gram index)
+   * and "these 5 symbols start a keyword" (key = index * W + class of the 5th symbol).  An item
+   * that is in neither needs no record: 4 of 5 on config 3 (19.6 % of the positions pass the
+   * 4-gram bits, 3.2 % have something to report or to walk on from), and the record gather --
+   * 64 lanes, 64 lines, two thirds of them L2 misses on a 4 MB table -- is what the kernel waits
+   * for.  bloom5_bits == 0: no filters. */
+  uint32_t bloom_off, bloomT_bits, bloom5_bits;
   uint32_t R;             /* groups per tile */
   uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
 };
 
 constexpr uint32_t WIDE_H1 = 0x9E3779B1u, WIDE_H2 = 0x85EBCA6Bu; /* multiplicative hashes: Bloom bits, table slots */
+/* the two bit positions of a key in a Bloom filter of m bits (m < 2^24; host and device alike) */
+__host__ __device__ __forceinline__ uint32_t
+gram_bloom_slot (uint32_t key, uint32_t m, int which) {
+  const uint32_t h = which ? (key * WIDE_H2) ^ ((key * WIDE_H1) >> 15) : key * WIDE_H1;
+  return (uint32_t)(((uint64_t)h * m) >> 32);
+}
 constexpr uint32_t WT_TERM = 0x80000000u, WT_KIDS = 0x40000000u;
 
 template <bool COUNT_ONLY, bool SHORTS, bool WIDE>
@@ -64,8 +78,9 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   {
     uint4 *dst = reinterpret_cast<uint4 *> (smem);
     const uint4 *src = reinterpret_cast<const uint4 *> (K.g4bits);
-    for (uint32_t i = threadIdx.x; i < (K.g3_off + K.g3_bytes + 15) / 16; i += blockDim.x)
-      dst[i] = src[i]; /* 4-gram bits, then (g3_off) the nibbles of the short keywords */
+    const uint32_t image = K.bloom5_bits ? K.bloom_off + (K.bloomT_bits + K.bloom5_bits + 7) / 8 : K.g3_off + K.g3_bytes;
+    for (uint32_t i = threadIdx.x; i < (image + 15) / 16; i += blockDim.x)
+      dst[i] = src[i]; /* 4-gram bits, then (g3_off) the nibbles of the short keywords, then (bloom_off) the Bloom filters */
   }
   constexpr uint32_t NQ = SHORTS ? 3 : 2; /* queues per wave */
   uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (NQ * QCAP + HITS_STRIDE) * 8);
@@ -146,7 +161,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       /* a keyword of length 4 ends here: reported at once, its record needs nothing but the
        * state id (the trie records of the 508,339 states are 16 MB of HBM: not worth a visit) */
       const bool term = valid && (pend_rec[0].x >> 31) && pend_item[0].x + 3 >= E.emit_from;
-      emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, pend_rec[0].y, lane, hits, counted);
+      emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, (pend_rec[0].y - K.d4_begin) | HIT_LEN4, lane, hits, counted);
       if (!COUNT_ONLY)
         counted = uniform ((uint32_t)counted);
       const bool pass = valid && ((pend_rec[0].x >> (WIDE ? 0u : c4)) & 1u);
@@ -174,8 +189,23 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     pend_item[GRAM_DEPTH - 1] = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
     if (WIDE)
       pend_rec[GRAM_DEPTH - 1] = K.wtab[(pend_item[GRAM_DEPTH - 1].y * WIDE_H2) >> (32 - K.wtab_log2)];
-    else
-      pend_rec[GRAM_DEPTH - 1] = K.g4rec[pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu];
+    else {
+      const uint32_t idx = pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu;
+      bool need = lane < n_items;
+      if (K.bloom5_bits) {
+        auto bit = [&] (uint32_t slot) -> uint32_t {
+          const uint32_t w = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (K.bloom_off + (slot >> 5) * 4u);
+          return (w >> (slot & 31u)) & 1u;
+        };
+        const uint32_t key5 = __umul24 (idx, K.W) + (pend_item[GRAM_DEPTH - 1].y >> 20);
+        const uint32_t t = bit (gram_bloom_slot (idx, K.bloomT_bits, 0)) & bit (gram_bloom_slot (idx, K.bloomT_bits, 1));
+        const uint32_t f = bit (K.bloomT_bits + gram_bloom_slot (key5, K.bloom5_bits, 0)) &
+                           bit (K.bloomT_bits + gram_bloom_slot (key5, K.bloom5_bits, 1));
+        need = need && ((t | f) != 0);
+      }
+      /* (a lane that needs nothing asks for nothing: the gather costs by the line) */
+      pend_rec[GRAM_DEPTH - 1] = need ? K.g4rec[idx] : make_uint2 (0, 0);
+    }
     pend_n[GRAM_DEPTH - 1] = n_items;
   };
 

@@ -105,7 +105,7 @@ scan_sieve_kernel (SieveK S, EmitCtx E, Launch A, const unsigned char *__restric
     if (pend_n[0]) {
       const bool valid = lane < pend_n[0] && pend_a[0].y != 0;
       const bool term = valid && (pend_a[0].x >> 31) && pend_pos[0] + 3 >= E.emit_from;
-      emit_terminals<COUNT_ONLY> (E, term, pend_pos[0] + 3, pend_a[0].y, lane, hits, counted);
+      emit_terminals<COUNT_ONLY> (E, term, pend_pos[0] + 3, (pend_a[0].y - K.d4_begin) | HIT_LEN4, lane, hits, counted);
       if (!COUNT_ONLY)
         counted = uniform ((uint32_t)counted);
       const bool pass = valid && ((pend_a[0].x >> pend_c4[0]) & 1u);
