@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "acm_internal.h"
@@ -233,6 +234,20 @@ struct ACMPlan {
   uint32_t regions = 0, region_items = 0;
   uint64_t segment = SEGMENT;
   uint64_t generation = 0; /* for the machine-cached plan */
+  /* Dictionary growth without a rebuild (acm_gpu_plan_update): the keywords a machine got after
+   * this plan was made live in a small second plan, `delta`, scanned right after this one into the
+   * same record buffer (the match set of a dictionary is the union of its keywords' match sets;
+   * the delta's keyword ids start at kw_base).  A replaced delta waits in `retired` until the
+   * stream that may still be scanning with it has passed an event. */
+  ACMPlan *delta = nullptr;
+  uint32_t covered_keywords = 0; /* keywords of the machine this plan and its delta report */
+  uint32_t kw_base = 0;          /* added to the keyword ids of this plan's records (delta plans) */
+  uint32_t merges = 0;           /* updates that rebuilt everything */
+  struct Retired {
+    ACMPlan *plan;
+    hipEvent_t done; /* nullptr until the first scan after the retirement has recorded it */
+  };
+  std::vector<Retired> retired;
   /* ACM_GPU_EXPAND (experiments): 2 = expand_items_once_kernel, one atomic per block (default:
    * config 2 step 0.3202 -> 0.3182 ms); 0 = expand_items_kernel, one atomic per round of 1024
    * items.  (Tried: no parking at all, every wave expanding its own queue inside the scan kernel:
@@ -441,6 +456,7 @@ struct GramImage {
   uint32_t *bits, *g4, *rec, *edge, *g4gid; /* first-stage bits, second-stage records, trie records (depth-first), their edges, depth-4 state -> record */
   unsigned char *nib;                      /* narrow alphabets: nibble per 3-gram */
   uint32_t *tri;                           /* trigram sieve kernel: [W * W] words, bit c2 of word c0 * W + c1 (NULL: not wanted) */
+  uint32_t *prefix, *entry;                /* narrow alphabets: set bits before each word of `bits`; children mask | terminal << 31 by rank */
   uint32_t *bloom;                         /* narrow alphabets: Bloom bits, terminal 4-grams then 5-grams (GramK::bloom5_bits; NULL: none) */
   uint32_t bloomT_bits, bloom5_bits, lo;
   uint32_t *g3, *stab;                     /* short keywords: prefix states per 3-gram (narrow) / table of tagged windows (wide) */
@@ -513,6 +529,7 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     bits[idx >> 5] |= 1u << (idx & 31);
     g4[2 * (size_t)idx] = mask;
     g4[2 * (size_t)idx + 1] = st;
+    G.entry[st - fv.depth_start[4]] = mask;
     if (G.bloom) {
       auto set = [&] (uint32_t slot) { G.bloom[slot >> 5] |= 1u << (slot & 31); };
       if (fv.term_kw[st] != NONE) {
@@ -524,6 +541,14 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
         set (G.bloomT_bits + gram_bloom_slot (key5, G.bloom5_bits, 0));
         set (G.bloomT_bits + gram_bloom_slot (key5, G.bloom5_bits, 1));
       }
+    }
+  }
+  if (!G.wide) {
+    const uint32_t words = (G.W * G.W * G.W * G.W + 31) / 32;
+    uint32_t acc = 0;
+    for (uint32_t w = 0; w < words; w++) {
+      G.prefix[w] = acc;
+      acc += (uint32_t)__builtin_popcount (bits[w]);
     }
   }
   if (G.shorts && G.wide) {
@@ -562,8 +587,19 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
 
 } // namespace
 
+namespace {
+int plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan **out);
+}
+
 extern "C" int
 acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
+  return plan_create_flat_kw (flat, device, 0, out);
+}
+
+namespace {
+/* kw_base: added to every keyword id the plan reports (the delta plans of acm_gpu_plan_update) */
+int
+plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan **out) {
   if (!flat || !out)
     return ACM_GPU_E_ARG;
   int ndev = 0;
@@ -572,8 +608,24 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   if (device < 0 || device >= ndev)
     return ACM_GPU_E_ARG;
   HIP_TRY (hipSetDevice (device));
+  /* (asked once per device: the call takes a good part of a millisecond, and the delta plans of
+   * acm_gpu_plan_update are made at every dictionary change) */
+  static std::mutex prop_mutex;
+  static std::vector<std::pair<int, hipDeviceProp_t>> prop_cache;
   hipDeviceProp_t prop;
-  HIP_TRY (hipGetDeviceProperties (&prop, device));
+  {
+    std::lock_guard<std::mutex> g (prop_mutex);
+    bool have = false;
+    for (const auto &c : prop_cache)
+      if (c.first == device) {
+        prop = c.second;
+        have = true;
+      }
+    if (!have) {
+      HIP_TRY (hipGetDeviceProperties (&prop, device));
+      prop_cache.emplace_back (device, prop);
+    }
+  }
 
   ACMFlatInfo fi;
   ACMFlatView fv;
@@ -593,6 +645,8 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     return ACM_GPU_E_NOMEM;
   p->device = device;
   p->finfo = fi;
+  p->kw_base = kw_base;
+  p->covered_keywords = fi.n_keywords;
   p->text_sym_bytes = interned ? 8 : fi.sym_bytes;
   p->cu_count = prop.multiProcessorCount;
 
@@ -731,7 +785,8 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
    * of the record gather (GramK::bloom5_bits): 8 to 16 bits per terminal 4-gram, the rest for the
    * 5-grams; not worth it below 4 bits per 5-gram or for dictionaries of a few hundred keywords */
   uint32_t bloom_off = 0, bloomT_bits = 0, bloom5_bits = 0;
-  if (gram && !gram_wide && n_depth4 >= 2048) {
+  const char *bloom_env = getenv ("ACM_GPU_BLOOM"); /* 0: no Bloom filters (experiments) */
+  if (gram && !gram_wide && n_depth4 >= 2048 && !(bloom_env && atoi (bloom_env) == 0)) {
     const uint32_t lds_cap = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
     const uint32_t gq_bytes = (SPARSE_THREADS / WAVE) * ((gram_shorts ? 3 : 2) * QCAP + HITS_STRIDE) * 8;
     bloom_off = (g3_off + g3_bytes + 15) & ~15u;
@@ -763,6 +818,8 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   const size_t o_gedge = blob_reserve (cur, gram ? (size_t)fi.n_edges * 8 : 0);
   const size_t o_g4gid = blob_reserve (cur, gram ? (size_t)(fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1] - fv.depth_start[4]) * 4 + 16 : 0);
   const size_t o_kw4 = blob_reserve (cur, gram ? (size_t)n_depth4 * 4 + 16 : 0);
+  const size_t o_g4prefix = blob_reserve (cur, gram && !gram_wide ? (size_t)g4words * 4 + 16 : 0);
+  const size_t o_g4entry = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth4 * 4 + 16 : 0);
   const bool sieve = gram && sieve_want;
   const size_t o_tri = blob_reserve (cur, sieve ? (size_t)gW * gW * 4 + 16 : 0);
   p->blob_bytes = cur;
@@ -781,7 +838,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
       oi[4 * s + 0] = nb;
       oi[4 * s + 1] = nb ? fv.out_link[t0] : 0;
       oi[4 * s + 2] = nb ? fv.depth[t0] : 0;
-      oi[4 * s + 3] = nb ? fv.term_kw[t0] : 0;
+      oi[4 * s + 3] = nb ? fv.term_kw[t0] + kw_base : 0;
     }
   }
   memcpy (&host[o_dstart], fv.depth_start, ((size_t)fi.lmax + 2) * 4);
@@ -808,8 +865,10 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     G.g3 = reinterpret_cast<uint32_t *> (&host[o_g3rec]);
     G.stab = reinterpret_cast<uint32_t *> (&host[o_stab]);
     for (uint32_t st = fv.depth_start[4]; st < fv.depth_start[5]; st++)
-      reinterpret_cast<uint32_t *> (&host[o_kw4])[st - fv.depth_start[4]] = fv.term_kw[st];
+      reinterpret_cast<uint32_t *> (&host[o_kw4])[st - fv.depth_start[4]] = fv.term_kw[st] == NONE ? NONE : fv.term_kw[st] + kw_base;
     G.tri = sieve ? reinterpret_cast<uint32_t *> (&host[o_tri]) : nullptr;
+    G.prefix = reinterpret_cast<uint32_t *> (&host[o_g4prefix]);
+    G.entry = reinterpret_cast<uint32_t *> (&host[o_g4entry]);
     G.bloom = bloom5_bits ? reinterpret_cast<uint32_t *> (&host[o_g4bits + bloom_off]) : nullptr;
     G.bloomT_bits = bloomT_bits;
     G.bloom5_bits = bloom5_bits;
@@ -887,6 +946,8 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
     const uint32_t bits_bytes = bloom5_bits ? bloom_off + bloom_bytes : g3_off + g3_bytes;
     if ((uint64_t)bits_bytes + gq + WALK_CTX_BYTES <= lds_total) {
       p->d_kw4 = u32p (o_kw4);
+      p->GK.g4prefix = u32p (o_g4prefix);
+      p->GK.g4entry = u32p (o_g4entry);
       p->GK.bloom_off = bloom_off;
       p->GK.bloomT_bits = bloomT_bits;
       p->GK.bloom5_bits = bloom5_bits;
@@ -1105,6 +1166,7 @@ acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out) {
   *out = p;
   return ACM_GPU_OK;
 }
+} // namespace
 
 extern "C" int
 acm_gpu_plan_create (ACMachine *machine, int device, ACMPlan **out) {
@@ -1135,6 +1197,17 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
   if (!plan)
     return;
   (void)hipSetDevice (plan->device);
+  if (plan->delta || !plan->retired.empty ())
+    (void)hipDeviceSynchronize (); /* scans with a retired delta may still be in flight */
+  for (auto &r : plan->retired) {
+    if (r.done)
+      (void)hipEventDestroy (r.done);
+    acm_gpu_plan_destroy (r.plan);
+  }
+  plan->retired.clear ();
+  if (plan->delta)
+    acm_gpu_plan_destroy (plan->delta);
+  plan->delta = nullptr;
   for (auto &ev : plan->events) {
     (void)hipEventDestroy (ev.first);
     (void)hipEventDestroy (ev.second);
@@ -1168,6 +1241,8 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
 extern "C" void
 acm_gpu_plan_info (const ACMPlan *plan, ACMPlanInfo *info) {
   *info = plan->info;
+  info->delta_keywords = plan->delta ? plan->delta->finfo.n_keywords : 0;
+  info->merges = plan->merges;
 }
 
 extern "C" int
@@ -1180,7 +1255,9 @@ acm_gpu_plan_status (ACMPlan *plan) {
     return ACM_GPU_OK;
   unsigned int words[4] = { 0, 0, 0, 0 };
   HIP_TRY (hipMemcpy (words, plan->d_total, sizeof words, hipMemcpyDeviceToHost));
-  return words[3] ? ACM_GPU_E_INTERNAL : ACM_GPU_OK;
+  if (words[3])
+    return ACM_GPU_E_INTERNAL;
+  return plan->delta ? acm_gpu_plan_status (plan->delta) : ACM_GPU_OK;
 }
 
 extern "C" int
@@ -1753,7 +1830,9 @@ classmap_text (ACMPlan *p, const void *d_text, uint64_t n, hipStream_t st) {
 template <bool COUNT_ONLY>
 int
 scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint64_t pos_base, ACMRecord *d_records,
-           uint64_t capacity, uint64_t *d_count, hipStream_t st, bool accumulate = false) {
+           uint64_t capacity, uint64_t *d_count, hipStream_t st, bool accumulate = false, unsigned long long *shared_total = nullptr) {
+  /* shared_total (with accumulate): the running total of ANOTHER plan to add to -- a delta plan
+   * appends its records to those of the plan it belongs to */
   /* accumulate (streaming): records are appended after those of earlier calls -- the plan's
    * running total keeps counting and is handed over by acm_gpu_stream_finish, not here */
   HIP_TRY (hipSetDevice (p->device));
@@ -1806,7 +1885,7 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   EmitCtx E{};
   E.oinfo = p->d_oinfo;
   E.records = d_records;
-  E.count = (use_dense || accumulate) ? p->d_total : reinterpret_cast<unsigned long long *> (d_count);
+  E.count = shared_total ? shared_total : ((use_dense || accumulate) ? p->d_total : reinterpret_cast<unsigned long long *> (d_count));
   E.capacity = COUNT_ONLY ? 0 : capacity;
   E.wrows = p->d_wrows;
   E.cont_dh = p->d_cont_dh;
@@ -1867,6 +1946,33 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   return ACM_GPU_OK;
 }
 
+/* a plan and, if it has one, its delta (acm_gpu_plan_update): both scans append to the same record
+ * buffer through the plan's running total, handed to the caller's counter at the end */
+template <bool COUNT_ONLY>
+int
+scan_plan (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint64_t pos_base, ACMRecord *d_records,
+           uint64_t capacity, uint64_t *d_count, hipStream_t st, bool accumulate = false) {
+  if (!p->retired.empty ()) {
+    HIP_TRY (hipSetDevice (p->device));
+    /* deltas replaced since the last scan: whatever may still use them is on this stream, in front of this mark */
+    for (auto &r : p->retired)
+      if (!r.done) {
+        HIP_TRY (hipEventCreateWithFlags (&r.done, hipEventDisableTiming));
+        HIP_TRY (hipEventRecord (r.done, st));
+      }
+  }
+  if (!p->delta)
+    return scan_impl<COUNT_ONLY> (p, d_text, n, emit_from, pos_base, d_records, capacity, d_count, st, accumulate);
+  int rc = scan_impl<COUNT_ONLY> (p, d_text, n, emit_from, pos_base, d_records, capacity, d_count, st, true);
+  if (!rc)
+    rc = scan_impl<COUNT_ONLY> (p->delta, d_text, n, emit_from, pos_base, d_records, capacity, d_count, st, true, p->d_total);
+  if (!accumulate) { /* (also after a failure: the total must not leak into the next scan) */
+    hipLaunchKernelGGL (finish_count_kernel, dim3 (1), dim3 (64), 0, st, p->d_total, reinterpret_cast<unsigned long long *> (d_count));
+    HIP_TRY (hipGetLastError ());
+  }
+  return rc;
+}
+
 } // namespace
 
 extern "C" int
@@ -1874,7 +1980,7 @@ acm_gpu_scan_device (ACMPlan *plan, const void *d_text, uint64_t n_symbols, uint
                      ACMRecord *d_records, uint64_t capacity, uint64_t *d_count, void *stream) {
   if (!plan || !d_count || (n_symbols && !d_text) || (capacity && !d_records))
     return ACM_GPU_E_ARG;
-  return scan_impl<false> (plan, d_text, n_symbols, emit_from, pos_base, d_records, capacity, d_count,
+  return scan_plan<false> (plan, d_text, n_symbols, emit_from, pos_base, d_records, capacity, d_count,
                            static_cast<hipStream_t> (stream));
 }
 
@@ -1883,7 +1989,7 @@ acm_gpu_count_device (ACMPlan *plan, const void *d_text, uint64_t n_symbols, uin
                       void *stream) {
   if (!plan || !d_count || (n_symbols && !d_text))
     return ACM_GPU_E_ARG;
-  return scan_impl<true> (plan, d_text, n_symbols, emit_from, 0, nullptr, 0, d_count, static_cast<hipStream_t> (stream));
+  return scan_plan<true> (plan, d_text, n_symbols, emit_from, 0, nullptr, 0, d_count, static_cast<hipStream_t> (stream));
 }
 
 /* ------------------------------------------------------------------ streaming scan
@@ -1979,7 +2085,7 @@ acm_gpu_stream_feed (ACMStream *s, const void *text, uint64_t n_symbols) {
       HIP_TRY (hipMemcpyAsync (piece_at - ctx * s->sb, tail, (size_t)ctx * s->sb, hipMemcpyDeviceToDevice, s->compute));
     }
     HIP_TRY (hipEventRecord (s->tail_read[prev], s->compute));
-    int rc = scan_impl<false> (p, piece_at - ctx * s->sb, ctx + n, ctx, s->position - ctx, s->d_records, s->capacity, nullptr,
+    int rc = scan_plan<false> (p, piece_at - ctx * s->sb, ctx + n, ctx, s->position - ctx, s->d_records, s->capacity, nullptr,
                                s->compute, true);
     if (rc)
       return rc;
@@ -2166,9 +2272,8 @@ acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint64_t
 /* the reference's dictionaries grow while they are used (README.md:352-356,
  * generic_test.c:214-229).  Brings `plan` up to date with `machine` (the machine it was made from,
  * later): plans of the start-parallel kernel take the new keywords as edits of a few table words
- * (StartsMirror); the other kernels' tables are functions of the whole dictionary (a new keyword
- * changes a column of up to every failure-resolved row), so they are rebuilt -- 0.5 ms at 1,000
- * keywords -- behind the same handle. */
+ * (StartsMirror); every other plan keeps its tables and gets the new keywords as a small delta
+ * plan scanned beside it (below), merged into one plan again only now and then. */
 extern "C" int
 acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
   if (!plan || !machine)
@@ -2212,24 +2317,102 @@ acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
     plan->finfo.n_states = M.n_states;
     plan->finfo.n_edges = M.n_edges;
     plan->finfo.n_keywords = M.n_keywords;
+    plan->covered_keywords = M.n_keywords;
     plan->finfo.lmax = M.lmax;
     plan->generation = gen;
     return ACM_GPU_OK;
   }
-  /* rebuild behind the same handle (`gen` was read before the snapshot: keywords inserted while
-   * it is taken leave the plan stale, never wrongly fresh) */
+  /* Every other kind of plan has tables that are functions of the whole dictionary (a new keyword
+   * changes a column of up to every failure-resolved row, the rank of every later 4-gram ...).
+   * They are left alone: the keywords the machine got since the plan was made go into a small
+   * delta plan of their own, rebuilt from just those keywords at every update -- a cost that does
+   * not depend on the size of the dictionary -- and scanned after the plan itself (scan_plan).
+   * Only when the delta has grown past an eighth of the dictionary (at least 256 keywords) is
+   * everything rebuilt into one plan again.  (`gen` was read before the snapshots: keywords
+   * inserted while they are taken leave the plan stale, never wrongly fresh.) */
+  HIP_TRY (hipSetDevice (plan->device));
+  for (size_t i = 0; i < plan->retired.size ();) { /* deltas no scan can be using any more */
+    ACMPlan::Retired &r = plan->retired[i];
+    if (r.done && hipEventQuery (r.done) == hipSuccess) {
+      (void)hipEventDestroy (r.done);
+      acm_gpu_plan_destroy (r.plan);
+      plan->retired.erase (plan->retired.begin () + (long)i);
+    } else
+      i++;
+  }
+  const uint32_t base_kw = plan->finfo.n_keywords;
+  acm_internal_lock (machine);
+  const uint32_t nk = (uint32_t)acm_nb_keywords (machine);
+  if (nk < plan->covered_keywords) {
+    acm_internal_unlock (machine);
+    return ACM_GPU_E_ARG; /* not the machine this plan came from */
+  }
+  if (nk == plan->covered_keywords) {
+    acm_internal_unlock (machine);
+    plan->generation = gen;
+    return ACM_GPU_OK;
+  }
+  const uint32_t threshold = base_kw / 8 > 256 ? base_kw / 8 : 256;
+  const char *delta_env = getenv ("ACM_GPU_DELTA"); /* 0: always rebuild (experiments) */
+  if (nk - base_kw <= threshold && !(delta_env && atoi (delta_env) == 0)) {
+    /* the new keywords into a machine of their own: same comparator, the main machine's letters */
+    CMP_TYPE cmp;
+    void *cmp_arg;
+    acm_internal_comparator (machine, &cmp, &cmp_arg);
+    ACMachine *tm = acm_create (cmp, cmp_arg, 0);
+    MatchHolder h;
+    acm_matcher_init (&h);
+    int rc = ACM_GPU_OK;
+    uint32_t lmax = plan->finfo.lmax;
+    for (uint32_t k = base_kw; k < nk && rc == ACM_GPU_OK; k++) {
+      rc = acm_internal_get_keyword (machine, k, &h); /* the machine lock is held */
+      if (rc)
+        break;
+      ACState *cur = acm_initiate (tm);
+      for (size_t i = 0; i < h.length; i++)
+        acm_insert_letter_of_keyword (&cur, const_cast<void *> (h.letters[i]));
+      (void)acm_insert_end_of_keyword (&cur, 0, 0);
+      if (h.length > lmax)
+        lmax = (uint32_t)h.length;
+    }
+    acm_matcher_release (&h);
+    acm_internal_unlock (machine);
+    ACMFlat *flat = nullptr;
+    if (!rc)
+      rc = plan->d_classlut ? acm_flatten_classes (tm, plan->class_sym_bytes, &flat) : acm_flatten (tm, &flat);
+    acm_release (tm);
+    ACMPlan *fresh = nullptr;
+    if (!rc) {
+      rc = plan_create_flat_kw (flat, plan->device, base_kw, &fresh);
+      acm_flat_release (flat);
+    }
+    if (rc)
+      return rc;
+    fresh->class_sym_bytes = plan->class_sym_bytes;
+    fresh->segment = plan->segment;
+    if (plan->delta)
+      plan->retired.push_back (ACMPlan::Retired{ plan->delta, nullptr });
+    plan->delta = fresh;
+    plan->covered_keywords = nk;
+    plan->finfo.lmax = lmax; /* halos and sort keys go by the longest keyword of both */
+    plan->generation = gen;
+    return ACM_GPU_OK;
+  }
+  acm_internal_unlock (machine);
+  /* the delta has outgrown its share: one plan of everything, behind the same handle */
   ACMPlan *fresh = nullptr;
   int rc = plan->d_classlut ? acm_gpu_plan_create_classes (machine, plan->class_sym_bytes, plan->device, &fresh)
                             : acm_gpu_plan_create (machine, plan->device, &fresh);
   if (rc)
     return rc;
-  HIP_TRY (hipSetDevice (plan->device));
   HIP_TRY (hipDeviceSynchronize ()); /* scans in flight still read the old tables */
   const bool timing = plan->timing;
   const uint64_t segment = plan->segment;
+  const uint32_t merges = plan->merges + 1;
   std::swap (*plan, *fresh);
-  acm_gpu_plan_destroy (fresh);
+  acm_gpu_plan_destroy (fresh); /* the old tables, their delta and what was retired */
   plan->segment = segment;
+  plan->merges = merges;
   plan->generation = gen;
   if (timing)
     (void)acm_gpu_plan_timing (plan, 1);

@@ -55,6 +55,15 @@ struct GramK {
    * 64 lanes, 64 lines, two thirds of them L2 misses on a 4 MB table -- is what the kernel waits
    * for.  bloom5_bits == 0: no filters. */
   uint32_t bloom_off, bloomT_bits, bloom5_bits;
+  /* narrow alphabets: the second stage's records by RANK.  The depth-4 states are numbered in the
+   * order of their 4-gram index (breadth-first ids, children in symbol order), so the state of an
+   * existing 4-gram is d4_begin + its rank among the set bits of g4bits:
+   *   rank = g4prefix[index >> 5] + popcount (bits of its word below it),
+   * and g4entry[rank] = children mask | terminal << 31 is all the second stage needs: 66 KB + 4
+   * bytes per existing 4-gram (config 3: 360 KB) that stay in L2, where the 8-byte records by
+   * index (W^4 of them, 4.25 MB for a-z) did not fit beside the text streaming through: two of
+   * three record gathers went to memory for a 128-byte line each, 5.5 x the algorithmic bytes. */
+  const uint32_t *g4prefix, *g4entry;
   uint32_t R;             /* groups per tile */
   uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
 };
@@ -117,10 +126,13 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   /* batches of the first queue whose records are in flight: a pipeline of GRAM_DEPTH batches
    * (the gather of a batch has the time it takes the scan to fill that many more before it is
    * looked at: one batch ahead left the L2 / MALL latency exposed) */
-  constexpr int GRAM_DEPTH = 3;
+  constexpr int GRAM_DEPTH = WIDE ? 3 : 4; /* narrow: one more step, the record comes in two dependent lookups */
   DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_items = 0, d_b1 = 0, d_cons = 0, d_tiles = 0;)
   uint2 pend_item[GRAM_DEPTH], pend_rec[GRAM_DEPTH];
   uint32_t pend_n[GRAM_DEPTH]; /* wave-uniform: items in each pending batch, [0] the oldest */
+  /* narrow, newest batch only: the prefix count asked for, the rank inside the word | NEED */
+  uint32_t pend_pre = 0, pend_in = 0;
+  constexpr uint32_t PEND_NEED = 0x80000000u;
 #pragma unroll
   for (int d = 0; d < GRAM_DEPTH; d++) {
     pend_item[d] = make_uint2 (0, 0);
@@ -181,6 +193,12 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       pend_n[d] = pend_n[d + 1];
     }
     pend_n[GRAM_DEPTH - 1] = 0;
+    if (!WIDE && pend_n[GRAM_DEPTH - 2]) {
+      /* the batch that has just left the newest slot: its prefix counts are here, now the entries */
+      const uint32_t rank = pend_pre + (pend_in & ~PEND_NEED);
+      const uint32_t ent = (pend_in & PEND_NEED) ? K.g4entry[rank] : 0u;
+      pend_rec[GRAM_DEPTH - 2] = make_uint2 (ent, K.d4_begin + rank);
+    }
   };
   /* takes the newest n items of the first queue and sends for their records (the last pipeline
    * slot is free: consume_oldest ran just before) */
@@ -203,8 +221,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
                            bit (K.bloomT_bits + gram_bloom_slot (key5, K.bloom5_bits, 1));
         need = need && ((t | f) != 0);
       }
-      /* (a lane that needs nothing asks for nothing: the gather costs by the line) */
-      pend_rec[GRAM_DEPTH - 1] = need ? K.g4rec[idx] : make_uint2 (0, 0);
+      /* (a lane that needs nothing asks for nothing: a gather costs by the line) */
+      const uint32_t word = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
+      pend_in = __popc (word & ((1u << (idx & 31u)) - 1u)) | (need ? PEND_NEED : 0u);
+      pend_pre = need ? K.g4prefix[idx >> 5] : 0u;
+      pend_rec[GRAM_DEPTH - 1] = make_uint2 (0, 0);
     }
     pend_n[GRAM_DEPTH - 1] = n_items;
   };

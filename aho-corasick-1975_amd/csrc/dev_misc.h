@@ -121,3 +121,14 @@ synth_text_kernel (SYM *text, uint64_t n, uint64_t gbegin, uint32_t vocab, const
     text[li] = (SYM)v;
   }
 }
+
+/* ------------------------------------------------------------------ plans with a delta (acm_gpu_plan_update)
+ * the scans of a plan and of its delta add to one running total; this hands it to the caller's
+ * counter and leaves the total zero for the next scan */
+__global__ void
+finish_count_kernel (unsigned long long *total, unsigned long long *user_count) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *user_count = *total;
+    *total = 0;
+  }
+}

@@ -161,6 +161,8 @@ typedef struct {
   uint32_t chunk_bytes;  /* text bytes per lane-stream per tile */
   uint32_t streams;      /* independent streams per lane */
   uint64_t table_bytes;  /* device bytes held by the plan */
+  uint32_t delta_keywords; /* keywords added since the tables were made, held by the delta plan (acm_gpu_plan_update) */
+  uint32_t merges;         /* updates that rebuilt the tables (the delta had outgrown its share) */
 } ACMPlanInfo;
 
 /* Flattens `machine` and uploads the tables to `device`.  The plan is a snapshot: keywords
@@ -176,11 +178,18 @@ int acm_gpu_plan_create_flat (const ACMFlat *flat, int device, ACMPlan **out);
  * the text into a buffer the plan owns), then run the same kernels. */
 int acm_gpu_plan_create_classes (ACMachine *machine, uint32_t sym_bytes, int device, ACMPlan **out);
 /* Brings a plan up to date with the machine it was made from after keywords were added to it
- * (the reference inserts while it scans: README.md:352-356, generic_test.c:214-229).  Plans of
- * the start-parallel kernel (2- and 4-byte symbols) are edited in place: only the words of the new
- * keywords' own states change, and they are written on the stream of the next scan, in front of
- * it.  Plans of the other kernels are rebuilt behind the same handle.  Not while a stream
- * (acm_gpu_stream_*) is open on the plan.  acm_scan() calls this by itself. */
+ * (the reference inserts while it scans: README.md:352-356, generic_test.c:214-229), without
+ * rebuilding its tables and without waiting for the device:
+ *   - plans of the start-parallel kernel (2- and 4-byte symbols) are edited in place: only the
+ *     words of the new keywords' own states change, and they are written on the stream of the next
+ *     scan, in front of it;
+ *   - every other plan keeps its tables; the keywords added since it was made are flattened into a
+ *     small delta plan of their own (cost independent of the size of the dictionary), scanned
+ *     right after the plan into the same record buffer -- the match set of a dictionary is the
+ *     union of its keywords' match sets.  Once the delta holds more than an eighth of the
+ *     dictionary (at least 256 keywords) the next update builds one plan of everything again
+ *     (that one waits for the device).
+ * Not while a stream (acm_gpu_stream_*) is open on the plan.  acm_scan() calls this by itself. */
 int acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine);
 void acm_gpu_plan_destroy (ACMPlan *plan);
 void acm_gpu_plan_info (const ACMPlan *plan, ACMPlanInfo *info);

@@ -77,6 +77,47 @@ def test_acm_scan_on_machine_follows_dictionary_updates(torch_cuda):
     assert np.array_equal(m.scan_host(text), o.scan(text))
 
 
+def _novel_words(novel_bytes):
+    """generic_test.c:191-197: letters in lower case, everything else a blank"""
+    t = np.frombuffer(novel_bytes, np.uint8).copy()
+    upper = (t >= 65) & (t <= 90)
+    t[upper] += 32
+    t[~((t >= 97) & (t <= 122))] = 32
+    return t
+
+
+def test_dictionary_built_up_while_scanning_the_novel(torch_cuda, novel_bytes):
+    """The reference's second test (generic_test.c:166-239) on bytes: the dictionary is built up
+    from the text it is scanning -- every word met for the first time goes in as " word " -- and
+    matching goes on between the inserts, here through acm_scan() on the machine (the cached
+    plan follows the machine: acm_gpu_plan_update takes the new keywords as a delta plan and
+    rebuilds only now and then).  After EVERY insert a window of the text around the new word is
+    scanned and compared with the oracle holding the same dictionary; in the end 6,966 keywords
+     and the whole text against the oracle."""
+    text = _novel_words(novel_bytes)
+    m, o = build_pair([], 1, variant=po.MEYER85)
+    import re
+    seen, inserts = set(), 0
+    raw = text.tobytes()
+    for mt in re.finditer(rb"[a-z]+", raw):
+        w = mt.group(0)
+        if w in seen:
+            continue
+        seen.add(w)
+        kw = b" " + w + b" "
+        m.add_keyword(kw)
+        o.add_keyword(kw)
+        inserts += 1
+        lo, hi = max(mt.start() - 1500, 0), min(mt.end() + 1500, len(raw))
+        window = text[lo:hi]
+        got = m.scan_host(window)
+        want = o.scan(window)
+        assert got.size == want.size and np.array_equal(got, want), (inserts, w)
+    assert inserts == m.nb_keywords == 6966
+    want = o.scan(text)
+    assert np.array_equal(m.scan_host(text), want)
+
+
 def test_config1_novel(torch_cuda, novel_bytes):
     """BASELINE config 1 on the GPU path: 11,676 records, identical to the oracle's."""
     m, o = build_pair([b"he", b"she", b"his", b"hers"], 1)

@@ -39,3 +39,7 @@ def run(name, K, sym, N=300):
 
 run("bytes, 1k keywords", 1000, 1)
 run("uint32, 10k keywords", 10000, 4)
+if len(sys.argv) > 1 and sys.argv[1] == "big":
+    run("bytes, 100k keywords", 100000, 1, N=100)
+os.environ["ACM_GPU_DELTA"] = "0"
+run("bytes, 1k keywords, rebuild at every update (ACM_GPU_DELTA=0)", 1000, 1, N=100)
