@@ -50,7 +50,9 @@ class FlatView(C.Structure):
     _fields_ = [(n, C.POINTER(C.c_uint32)) for n in ("row_ptr", "edge_sym", "edge_next", "fail", "depth", "nb_outputs",
                                                      "term_kw", "out_link", "depth_start", "kw_state")] + [
         ("class_map", C.POINTER(C.c_uint16)), ("edge_letter", C.POINTER(C.c_uint32)), ("class_entries", C.c_uint32),
-        ("n_classes", C.c_uint32), ("keys64", C.POINTER(C.c_uint64)), ("n_keys64", C.c_uint32)]
+        ("n_classes", C.c_uint32), ("keys64", C.POINTER(C.c_uint64)), ("n_keys64", C.c_uint32),
+        ("keys32", C.POINTER(C.c_uint32)), ("keys32_class", C.POINTER(C.c_uint32)), ("n_keys32", C.c_uint32),
+        ("class_rep32", C.POINTER(C.c_uint32))]
 
 
 class PlanInfo(C.Structure):
@@ -223,6 +225,13 @@ class FlatTables:
         self.edge_letter = arr(v.edge_letter, ne) if v.class_entries else None
         # 8-byte symbols: edge_sym = 1 + index into keys64 (the dictionary's distinct symbols, ascending)
         self.keys64 = np.ctypeslib.as_array(v.keys64, shape=(v.n_keys64,)).copy() if v.n_keys64 else None
+        # comparator classes of 4-byte symbols: the dictionary's distinct symbols, their classes (1 .. n_classes),
+        # one symbol per class in comparator order
+        self.keys32 = arr(v.keys32, v.n_keys32) if v.n_keys32 else None
+        self.keys32_class = arr(v.keys32_class, v.n_keys32) if v.n_keys32 else None
+        self.class_rep32 = arr(v.class_rep32, v.n_classes) if v.n_keys32 else None
+        if v.n_keys32:
+            self.edge_letter = arr(v.edge_letter, ne)
 
     def dense_rows(self, n_rows=None, entry_bytes=None):
         info = self.info

@@ -25,6 +25,13 @@ struct ACMFlat {
    * dictionary (0 is kept for every other symbol of a text); keys64 are those symbols, ascending */
   uint64_t *keys64;
   uint32_t n_keys64;
+  /* 4-byte symbols flattened over comparator classes (acm_flatten_classes, sym_bytes 4): the
+   * 2^32 symbol values cannot be enumerated, so the classes are those of the dictionary's OWN
+   * symbols -- class 1 .. n_classes in comparator order, 0 for a symbol that compares equal to
+   * none of them -- and a text symbol is classified when it is first met (acm_gpu.hip) */
+  uint32_t *keys32, *keys32_class; /* the dictionary's distinct symbols by value, and their classes */
+  uint32_t n_keys32;
+  uint32_t *class_rep32;           /* [n_classes] one symbol of each class, in comparator order */
 };
 
 static uint32_t
@@ -111,14 +118,36 @@ acm_flat_release (ACMFlat *f) {
   free (f->class_map);
   free (f->edge_letter);
   free (f->keys64);
+  free (f->keys32);
+  free (f->keys32_class);
+  free (f->class_rep32);
   free (f);
 }
 
 /* class_map != NULL: symbols are replaced by their comparator class (ownership of class_map
  * passes to the flat tables on success) */
+/* class of symbol v among the n sorted keys (it is one of them) */
+static uint32_t
+key32_class (const uint32_t *keys, const uint32_t *classes, uint32_t n, uint32_t v) {
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (keys[mid] <= v)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return classes[lo];
+}
+
+struct keys32_arg {
+  uint32_t *keys, *classes, *reps;
+  uint32_t n, n_classes;
+};
+
 static int
 flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint32_t class_entries, uint32_t n_classes,
-              ACMFlat **out) {
+              ACMFlat **out, const struct keys32_arg *k32) {
 
   acm_internal_lock (machine); /* writers are excluded while the snapshot is taken */
   const uint32_t n = acm_internal_nb_states (machine);
@@ -137,7 +166,7 @@ flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint3
   f->out_link = malloc ((size_t)n * sizeof (uint32_t));
   if (!f->row_ptr || !f->edge_sym || !f->edge_next || !f->fail || !f->depth || !f->nb_outputs || !f->term_kw || !f->out_link)
     goto nomem;
-  if (class_map) {
+  if (class_map || k32) {
     f->edge_letter = malloc ((size_t)(n ? n : 1) * sizeof (uint32_t));
     if (!f->edge_letter)
       goto nomem;
@@ -180,12 +209,15 @@ flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint3
       if (class_map) {
         f->edge_letter[edges] = f->edge_sym[edges];
         f->edge_sym[edges] = class_map[f->edge_sym[edges]];
+      } else if (k32) {
+        f->edge_letter[edges] = f->edge_sym[edges];
+        f->edge_sym[edges] = key32_class (k32->keys, k32->classes, k32->n, f->edge_sym[edges]);
       }
       f->edge_next[edges] = tail;
       edges++;
       order[tail++] = k;
     }
-    if (sym_bytes > 1 && ACM_NKIDS (s) > 1 && !class_map) { /* class ids already ascend in comparator order */
+    if (sym_bytes > 1 && ACM_NKIDS (s) > 1 && !class_map && !k32) { /* class ids already ascend in comparator order */
       /* the comparator orders multi-byte symbols by memcmp; the device bisects rows by numeric
        * value, so re-order this row (and the ids just handed out) by value */
       if (sort_row_by_value (f->edge_sym + f->row_ptr[head], order + f->edge_next[f->row_ptr[head]], ACM_NKIDS (s)))
@@ -256,6 +288,13 @@ flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint3
   f->class_map = class_map;
   f->class_entries = class_map ? class_entries : 0;
   f->n_classes = class_map ? n_classes : 0;
+  if (k32) { /* ownership passes to the flat tables */
+    f->keys32 = k32->keys;
+    f->keys32_class = k32->classes;
+    f->class_rep32 = k32->reps;
+    f->n_keys32 = k32->n;
+    f->n_classes = k32->n_classes;
+  }
   *out = f;
   return ACM_GPU_OK;
 
@@ -275,7 +314,7 @@ acm_flatten (ACMachine *machine, ACMFlat **out) {
   int rc = acm_internal_symbol_bytes (machine, &sym_bytes);
   if (rc)
     return rc;
-  return flatten_impl (machine, sym_bytes, NULL, 0, 0, out);
+  return flatten_impl (machine, sym_bytes, NULL, 0, 0, out, 0);
 }
 
 /* ------------------------------------------------------------------ comparator classes
@@ -305,8 +344,130 @@ class_sort_cmp (const void *a, const void *b, void *ctxp) {
   return va < vb ? -1 : va > vb; /* keep the sort deterministic inside a class */
 }
 
+/* comparator classes of the dictionary's own 4-byte symbols (ACMFlat::keys32) */
+struct sym32_ctx {
+  CMP_TYPE cmp;
+  void *arg;
+};
+static int
+sym32_sort_cmp (const void *a, const void *b, void *ctxp) {
+  const struct sym32_ctx *ctx = ctxp;
+  const int c = ctx->cmp (a, b, ctx->arg); /* the values as they lie in memory: what a caller's letters look like */
+  if (c)
+    return c;
+  const uint32_t va = *(const uint32_t *)a, vb = *(const uint32_t *)b;
+  return va < vb ? -1 : va > vb;
+}
+struct key_class {
+  uint32_t key, cls;
+};
+static int
+key_class_cmp (const void *a, const void *b) {
+  const uint32_t x = ((const struct key_class *)a)->key, y = ((const struct key_class *)b)->key;
+  return x < y ? -1 : x > y;
+}
+
+static int
+flatten_classes32 (ACMachine *machine, ACMFlat **out) {
+  struct sym32_ctx ctx;
+  acm_internal_comparator (machine, &ctx.cmp, &ctx.arg);
+  /* every letter of the dictionary: one per state but the root (duplicates go away below) */
+  acm_internal_lock (machine);
+  const uint32_t n_states = acm_internal_nb_states (machine);
+  uint32_t *letters = malloc ((size_t)(n_states ? n_states : 1) * sizeof *letters);
+  struct _ac_state **stack = malloc ((size_t)(n_states ? n_states : 1) * sizeof *stack);
+  uint32_t nl = 0;
+  if (letters && stack) {
+    uint32_t top = 0;
+    stack[top++] = acm_internal_root (machine);
+    while (top) {
+      struct _ac_state *st = stack[--top];
+      for (uint32_t i = 0; i < ACM_NKIDS (st); i++) {
+        struct _ac_state *k = ACM_KID (st, i);
+        letters[nl++] = symbol_value (k->letter, 4);
+        stack[top++] = k;
+      }
+    }
+  }
+  acm_internal_unlock (machine);
+  const int walked = letters && stack;
+  free (stack);
+  if (!walked) {
+    free (letters);
+    return ACM_GPU_E_NOMEM;
+  }
+  qsort_r (letters, nl, sizeof *letters, sym32_sort_cmp, &ctx);
+  struct key_class *kc = malloc ((size_t)(nl ? nl : 1) * sizeof *kc);
+  uint32_t *reps = malloc ((size_t)(nl ? nl : 1) * sizeof *reps);
+  if (!kc || !reps) {
+    free (letters);
+    free (kc);
+    free (reps);
+    return ACM_GPU_E_NOMEM;
+  }
+  uint32_t nk = 0, n_classes = 0;
+  int consistent = 1;
+  for (uint32_t i = 0; i < nl && consistent; i++) {
+    if (i && letters[i] == letters[i - 1])
+      continue; /* the same symbol again */
+    int fresh = 1;
+    if (nk) {
+      const int ab = ctx.cmp (&reps[n_classes - 1], &letters[i], ctx.arg), ba = ctx.cmp (&letters[i], &reps[n_classes - 1], ctx.arg);
+      if (ab > 0 || ba < 0 || (ab == 0) != (ba == 0))
+        consistent = 0; /* not an order: sorted neighbours out of order either way */
+      fresh = ab != 0;
+    }
+    if (fresh)
+      reps[n_classes++] = letters[i];
+    kc[nk].key = letters[i];
+    kc[nk].cls = n_classes; /* classes 1 .. n_classes; 0 is "equal to no symbol of the dictionary" */
+    nk++;
+  }
+  /* the sort only compared neighbours: the representatives against one another too (all pairs up
+   * to 1024 classes, pairs at power-of-two distances beyond) */
+  for (uint32_t i = 0; i < n_classes && consistent; i++)
+    for (uint32_t step = 1; i + step < n_classes && consistent; step = n_classes <= 1024 ? step + 1 : step * 2)
+      consistent = ctx.cmp (&reps[i], &reps[i + step], ctx.arg) < 0 && ctx.cmp (&reps[i + step], &reps[i], ctx.arg) > 0;
+  free (letters);
+  if (!consistent) {
+    free (kc);
+    free (reps);
+    return ACM_GPU_E_INELIGIBLE;
+  }
+  qsort (kc, nk, sizeof *kc, key_class_cmp);
+  struct keys32_arg k32;
+  k32.keys = malloc ((size_t)(nk ? nk : 1) * sizeof (uint32_t));
+  k32.classes = malloc ((size_t)(nk ? nk : 1) * sizeof (uint32_t));
+  k32.reps = reps;
+  k32.n = nk;
+  k32.n_classes = n_classes;
+  if (!k32.keys || !k32.classes) {
+    free (kc);
+    free (reps);
+    free (k32.keys);
+    free (k32.classes);
+    return ACM_GPU_E_NOMEM;
+  }
+  for (uint32_t i = 0; i < nk; i++) {
+    k32.keys[i] = kc[i].key;
+    k32.classes[i] = kc[i].cls;
+  }
+  free (kc);
+  /* (a keyword inserted between the walk above and the snapshot below would bring a symbol without
+   * a class: the caller holds the dictionary still, as for every flatten of a plan it then uses) */
+  int rc = flatten_impl (machine, 4, NULL, 0, 0, out, &k32);
+  if (rc) {
+    free (k32.keys);
+    free (k32.classes);
+    free (reps);
+  }
+  return rc;
+}
+
 int
 acm_flatten_classes (ACMachine *machine, uint32_t sym_bytes, ACMFlat **out) {
+  if (machine && out && sym_bytes == 4)
+    return flatten_classes32 (machine, out);
   if (!machine || !out || (sym_bytes != 1 && sym_bytes != 2))
     return ACM_GPU_E_ARG;
   struct class_sort_ctx ctx;
@@ -375,7 +536,7 @@ acm_flatten_classes (ACMachine *machine, uint32_t sym_bytes, ACMFlat **out) {
     free (class_map);
     return ACM_GPU_E_INELIGIBLE;
   }
-  int rc = flatten_impl (machine, sym_bytes, class_map, V, n_classes, out);
+  int rc = flatten_impl (machine, sym_bytes, class_map, V, n_classes, out, 0);
   if (rc)
     free (class_map);
   return rc;
@@ -404,6 +565,10 @@ acm_flat_view (const ACMFlat *f, ACMFlatView *v) {
   v->n_classes = f->n_classes;
   v->keys64 = f->keys64;
   v->n_keys64 = f->n_keys64;
+  v->keys32 = f->keys32;
+  v->keys32_class = f->keys32_class;
+  v->n_keys32 = f->n_keys32;
+  v->class_rep32 = f->class_rep32;
 }
 
 /* Failure-resolved rows.  Row 0: goto or stay at the root.  Row s > 0: copy of row f(s) (already
@@ -487,7 +652,7 @@ acm_flat_blob_bytes (const ACMFlat *f) {
 
 int
 acm_flat_to_blob (const ACMFlat *f, void *out, size_t capacity) {
-  if (!f || !out || capacity < acm_flat_blob_bytes (f))
+  if (!f || !out || capacity < acm_flat_blob_bytes (f) || f->keys32 /* classes of 4-byte symbols need their comparator */)
     return ACM_GPU_E_ARG;
 
   const ACMFlatInfo *in = &f->info;

@@ -37,6 +37,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "acm_internal.h"
@@ -229,6 +230,19 @@ struct ACMPlan {
   uint4 *d_intern = nullptr;
   uint32_t intern_mask = 0;
   uint32_t text_sym_bytes = 0; /* symbol size of the caller's text (== finfo.sym_bytes unless interned) */
+  /* comparator classes of 4-byte symbols (ACMFlatView::keys32): every symbol classified so far ->
+   * class, on the host and as the device's table {symbol, class + 1}; the text is mapped to class
+   * ids into d_remap before every scan and symbols met for the first time are classified on the
+   * host with the machine's comparator (cmp32; classify_text32) */
+  bool cls32 = false;
+  std::unordered_map<uint32_t, uint32_t> cls32_known;
+  std::vector<uint32_t> cls32_reps; /* one symbol per class, comparator order: class i + 1 */
+  CMP_TYPE cmp32 = nullptr;
+  void *cmp32_arg = nullptr;
+  unsigned long long *d_cls32 = nullptr;
+  uint32_t cls32_slots = 0, cls32_uploaded = 0; /* table size; known symbols it holds */
+  uint32_t *d_unknown = nullptr; /* [0] count, [1 ..] symbols */
+  static constexpr uint32_t CLS32_UNKNOWN_CAP = 1u << 16;
   void *d_remap = nullptr;
   size_t remap_bytes = 0;
   uint32_t regions = 0, region_items = 0;
@@ -1146,6 +1160,16 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     }
     p->intern_mask = cap - 1;
   }
+  if (fv.keys32 || (fi.sym_bytes == 4 && fv.class_rep32)) {
+    p->cls32 = true;
+    for (uint32_t i = 0; i < fv.n_keys32; i++)
+      p->cls32_known[fv.keys32[i]] = fv.keys32_class[i];
+    p->cls32_reps.assign (fv.class_rep32, fv.class_rep32 + fv.n_classes);
+    if (hipMalloc (reinterpret_cast<void **> (&p->d_unknown), (size_t)(ACMPlan::CLS32_UNKNOWN_CAP + 1) * 4) != hipSuccess) {
+      acm_gpu_plan_destroy (p);
+      return ACM_GPU_E_NOMEM;
+    }
+  }
   if (fv.class_map) {
     /* 65,536 entries either way: 2-byte symbols directly, bytes in pairs (see classmap_kernel) */
     std::vector<uint16_t> lut (65536);
@@ -1187,8 +1211,11 @@ acm_gpu_plan_create_classes (ACMachine *machine, uint32_t sym_bytes, int device,
     return rc;
   rc = acm_gpu_plan_create_flat (flat, device, out);
   acm_flat_release (flat);
-  if (!rc)
+  if (!rc) {
     (*out)->class_sym_bytes = sym_bytes;
+    if ((*out)->cls32) /* symbols a text brings are classified with the machine's own comparator */
+      acm_internal_comparator (machine, &(*out)->cmp32, &(*out)->cmp32_arg);
+  }
   return rc;
 }
 
@@ -1231,6 +1258,10 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
   }
   if (plan->d_intern)
     (void)hipFree (plan->d_intern);
+  if (plan->d_cls32)
+    (void)hipFree (plan->d_cls32);
+  if (plan->d_unknown)
+    (void)hipFree (plan->d_unknown);
   if (plan->d_classlut)
     (void)hipFree (plan->d_classlut);
   if (plan->d_remap)
@@ -1827,6 +1858,102 @@ classmap_text (ACMPlan *p, const void *d_text, uint64_t n, hipStream_t st) {
   return ACM_GPU_OK;
 }
 
+/* comparator classes of 4-byte symbols: class of a symbol the tables have not seen, by bisection
+ * among the class representatives with the machine's comparator (0: equal to none of them) */
+uint32_t
+classify_symbol32 (const ACMPlan *p, uint32_t sym) {
+  uint32_t lo = 0, hi = (uint32_t)p->cls32_reps.size ();
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    const int c = p->cmp32 (&sym, &p->cls32_reps[mid], p->cmp32_arg);
+    if (c == 0)
+      return mid + 1;
+    if (c < 0)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  return 0;
+}
+
+/* the device table from everything classified so far (grown to stay at most a quarter full) */
+int
+upload_cls32_table (ACMPlan *p, hipStream_t st) {
+  uint32_t slots = p->cls32_slots ? p->cls32_slots : 1u << 12;
+  while ((uint64_t)slots < 4ull * (p->cls32_known.size () + ACMPlan::CLS32_UNKNOWN_CAP))
+    slots <<= 1;
+  if (slots != p->cls32_slots) {
+    if (p->d_cls32) {
+      HIP_TRY (hipStreamSynchronize (st));
+      HIP_TRY (hipFree (p->d_cls32));
+      p->d_cls32 = nullptr;
+    }
+    if (hipMalloc (reinterpret_cast<void **> (&p->d_cls32), (size_t)slots * 8) != hipSuccess)
+      return ACM_GPU_E_NOMEM;
+    p->cls32_slots = slots;
+  }
+  std::vector<unsigned long long> tab (slots, 0ull);
+  auto mix = [] (uint64_t x) {
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+  };
+  for (const auto &kv : p->cls32_known) {
+    uint32_t h = (uint32_t)mix (kv.first) & (slots - 1);
+    while (tab[h])
+      h = (h + 1) & (slots - 1);
+    tab[h] = ((unsigned long long)(kv.second + 1) << 32) | kv.first;
+  }
+  HIP_TRY (hipMemcpyWithStream (p->d_cls32, tab.data (), (size_t)slots * 8, hipMemcpyHostToDevice, st));
+  p->cls32_uploaded = (uint32_t)p->cls32_known.size ();
+  return ACM_GPU_OK;
+}
+
+/* maps n 4-byte symbols of d_text to class ids into the plan's own buffer.  Symbols the plan has
+ * not met yet come back on a list, are classified here with the comparator and the pass is
+ * repeated: the call waits for the stream (once when the text brings nothing new). */
+int
+classify_text32 (ACMPlan *p, const void *d_text, uint64_t n, hipStream_t st) {
+  if (reinterpret_cast<uintptr_t> (d_text) & 3)
+    return ACM_GPU_E_ARG;
+  int rc = ensure_remap_buffer (p, (size_t)n * 4, st);
+  if (rc)
+    return rc;
+  if (!p->d_cls32 || p->cls32_uploaded != p->cls32_known.size ()) {
+    rc = upload_cls32_table (p, st);
+    if (rc)
+      return rc;
+  }
+  const uint64_t want_blocks = (n + 255) / 256;
+  const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)p->cu_count * 32 ? want_blocks : (uint64_t)p->cu_count * 32);
+  std::vector<uint32_t> fresh;
+  for (int round = 0; round < 1 << 20; round++) {
+    HIP_TRY (hipMemsetAsync (p->d_unknown, 0, 4, st));
+    hipLaunchKernelGGL (classify32_kernel, dim3 (grid), dim3 (256), 0, st, static_cast<const uint32_t *> (d_text),
+                        static_cast<uint32_t *> (p->d_remap), n, p->d_cls32, p->cls32_slots - 1, p->d_unknown + 1, p->d_unknown,
+                        ACMPlan::CLS32_UNKNOWN_CAP);
+    HIP_TRY (hipGetLastError ());
+    uint32_t cnt = 0;
+    HIP_TRY (hipMemcpyWithStream (&cnt, p->d_unknown, 4, hipMemcpyDeviceToHost, st));
+    if (cnt == 0)
+      return ACM_GPU_OK;
+    if (!p->cmp32)
+      return ACM_GPU_E_INELIGIBLE; /* tables without their machine: nothing to classify new symbols with */
+    const uint32_t listed = cnt < ACMPlan::CLS32_UNKNOWN_CAP ? cnt : ACMPlan::CLS32_UNKNOWN_CAP;
+    fresh.resize (listed);
+    HIP_TRY (hipMemcpyWithStream (fresh.data (), p->d_unknown + 1, (size_t)listed * 4, hipMemcpyDeviceToHost, st));
+    for (uint32_t sym : fresh)
+      if (!p->cls32_known.count (sym))
+        p->cls32_known[sym] = classify_symbol32 (p, sym);
+    rc = upload_cls32_table (p, st); /* also clears the slots claimed for symbols that did not fit the list */
+    if (rc)
+      return rc;
+  }
+  return ACM_GPU_E_INTERNAL;
+}
+
 template <bool COUNT_ONLY>
 int
 scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint64_t pos_base, ACMRecord *d_records,
@@ -1860,6 +1987,11 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     hipLaunchKernelGGL (intern_kernel, dim3 (grid), dim3 (256), 0, st, static_cast<const uint64_t *> (d_text),
                         static_cast<uint32_t *> (p->d_remap), n, p->d_intern, p->intern_mask);
     HIP_TRY (hipGetLastError ());
+    d_text = p->d_remap;
+  } else if (p->cls32) {
+    int rc = classify_text32 (p, d_text, n, st);
+    if (rc)
+      return rc;
     d_text = p->d_remap;
   } else if (p->d_classlut) {
     /* comparator-class plan: walk the class ids of the text (our own, aligned, copy) */
@@ -2281,7 +2413,7 @@ acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
   const uint64_t gen = acm_internal_generation (machine);
   uint32_t sym_bytes = 0;
   const bool plain = acm_internal_symbol_bytes (machine, &sym_bytes) == ACM_GPU_OK;
-  if (plan->mir && plan->starts && plain && !plan->d_classlut && sym_bytes == plan->finfo.sym_bytes) {
+  if (plan->mir && plan->starts && plain && !plan->class_sym_bytes && sym_bytes == plan->finfo.sym_bytes) {
     StartsMirror &M = *plan->mir;
     acm_internal_lock (machine);
     const uint32_t nk = (uint32_t)acm_nb_keywords (machine);
@@ -2379,7 +2511,7 @@ acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
     acm_internal_unlock (machine);
     ACMFlat *flat = nullptr;
     if (!rc)
-      rc = plan->d_classlut ? acm_flatten_classes (tm, plan->class_sym_bytes, &flat) : acm_flatten (tm, &flat);
+      rc = plan->class_sym_bytes ? acm_flatten_classes (tm, plan->class_sym_bytes, &flat) : acm_flatten (tm, &flat);
     acm_release (tm);
     ACMPlan *fresh = nullptr;
     if (!rc) {
@@ -2389,6 +2521,8 @@ acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
     if (rc)
       return rc;
     fresh->class_sym_bytes = plan->class_sym_bytes;
+    fresh->cmp32 = plan->cmp32;
+    fresh->cmp32_arg = plan->cmp32_arg;
     fresh->segment = plan->segment;
     if (plan->delta)
       plan->retired.push_back (ACMPlan::Retired{ plan->delta, nullptr });
@@ -2401,8 +2535,8 @@ acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
   acm_internal_unlock (machine);
   /* the delta has outgrown its share: one plan of everything, behind the same handle */
   ACMPlan *fresh = nullptr;
-  int rc = plan->d_classlut ? acm_gpu_plan_create_classes (machine, plan->class_sym_bytes, plan->device, &fresh)
-                            : acm_gpu_plan_create (machine, plan->device, &fresh);
+  int rc = plan->class_sym_bytes ? acm_gpu_plan_create_classes (machine, plan->class_sym_bytes, plan->device, &fresh)
+                                 : acm_gpu_plan_create (machine, plan->device, &fresh);
   if (rc)
     return rc;
   HIP_TRY (hipDeviceSynchronize ()); /* scans in flight still read the old tables */

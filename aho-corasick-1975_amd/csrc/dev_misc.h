@@ -65,6 +65,42 @@ intern_kernel (const uint64_t *__restrict__ in, uint32_t *__restrict__ out, uint
   }
 }
 
+/* ------------------------------------------------------------------ comparator classes of 4-byte symbols
+ * The text is mapped to class ids (what the tables were flattened over) through an open-addressing
+ * table {symbol, class + 1} that holds every symbol classified so far.  A symbol met for the first
+ * time claims a slot with the value CLS32_PENDING and goes on the list the host classifies with
+ * the machine's comparator; the pass is then repeated (its output was provisional). */
+constexpr uint32_t CLS32_PENDING = 0xFFFFFFFFu;
+__global__ void
+classify32_kernel (const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n, unsigned long long *table, uint32_t mask,
+                   uint32_t *unknown, uint32_t *unknown_count, uint32_t unknown_cap) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t k = in[i];
+    uint32_t h = (uint32_t)intern_hash (k) & mask, cls = 0;
+    for (uint32_t probes = 0; probes <= mask; probes++) {
+      unsigned long long slot = table[h]; /* {symbol, class + 1}; 0 = empty */
+      if ((uint32_t)(slot >> 32) == 0) {
+        const unsigned long long mine = ((unsigned long long)CLS32_PENDING << 32) | k;
+        const unsigned long long old = atomicCAS (&table[h], 0ull, mine);
+        if (old == 0) {
+          const uint32_t at = atomicAdd (unknown_count, 1u);
+          if (at < unknown_cap)
+            unknown[at] = k;
+          break;
+        }
+        slot = old;
+      }
+      if ((uint32_t)slot == k) {
+        const uint32_t v = (uint32_t)(slot >> 32);
+        cls = v == CLS32_PENDING ? 0u : v - 1u;
+        break;
+      }
+      h = (h + 1) & mask;
+    }
+    out[i] = cls;
+  }
+}
+
 /* ------------------------------------------------------------------ incremental updates
  * word patches for the tables of the start-parallel kernel: {table, index, value, -} */
 struct PatchTables {

@@ -99,6 +99,13 @@ typedef struct {
    * holds 1 + the index into this table (0 stands for every other symbol a text may hold) */
   const uint64_t *keys64;
   uint32_t n_keys64;
+  /* 4-byte symbols flattened over comparator classes only, else NULL / 0: the dictionary's distinct
+   * symbols (ascending by value) and their classes 1 .. n_classes (what edge_sym holds; 0 stands
+   * for a symbol that compares equal to none of them), and one symbol of each class in comparator
+   * order (a text symbol is classified against these when a scan first meets it) */
+  const uint32_t *keys32, *keys32_class;
+  uint32_t n_keys32;
+  const uint32_t *class_rep32;
 } ACMFlatView;
 
 int acm_flatten (ACMachine *machine, ACMFlat **out);
@@ -108,7 +115,12 @@ int acm_flatten (ACMachine *machine, ACMFlat **out);
  * tell apart; the tables are built over class ids and a plan made from them maps the text through
  * the class table on the device before walking it.  ACM_GPU_E_INELIGIBLE if the comparator is not
  * a consistent order over all values.  (The symbol size is an argument because a custom
- * comparator's cmp_arg is opaque.) */
+ * comparator's cmp_arg is opaque.)
+ * sym_bytes = 4 (the reference's own example: wchar_t with the case-insensitive alphacmp,
+ * generic_test.c:48-54,62-164): 2^32 values cannot be enumerated, so the classes are those of the
+ * dictionary's own symbols; a plan made from such tables classifies the symbols of a text when it
+ * first meets them, with the machine's comparator, on the host (ACMFlatView::keys32).  Such tables
+ * have no serialised form (acm_flat_to_blob: ACM_GPU_E_ARG). */
 int acm_flatten_classes (ACMachine *machine, uint32_t sym_bytes, ACMFlat **out);
 void acm_flat_release (ACMFlat *flat);
 void acm_flat_info (const ACMFlat *flat, ACMFlatInfo *info);

@@ -32,6 +32,7 @@ def kat():
     L.kat_srand.argtypes = [C.c_uint]
     L.kat_read_novel.restype = C.c_long
     L.kat_read_novel.argtypes = [C.c_char_p, C.c_void_p, C.c_long]
+    L.setlocale_utf8 = L.kat_setlocale_utf8
     return L
 
 

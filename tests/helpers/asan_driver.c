@@ -39,6 +39,17 @@ casecmp8 (const void *a, const void *b, const void *arg) {
   return x > y ? 1 : (x < y ? -1 : 0);
 }
 
+static int
+casecmp32 (const void *a, const void *b, const void *arg) {
+  (void)arg;
+  uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+  if (x >= 'A' && x <= 'Z')
+    x += 32;
+  if (y >= 'A' && y <= 'Z')
+    y += 32;
+  return x > y ? 1 : (x < y ? -1 : 0);
+}
+
 /* builds a machine of n_kw random keywords over `vocab` symbols of sym_bytes bytes */
 static ACMachine *
 build (size_t sym_bytes, size_t *arg, unsigned n_kw, unsigned vocab, unsigned char **letters_out, CMP_TYPE cmp) {
@@ -147,7 +158,30 @@ main (void) {
     CHECK (v.class_map && v.class_entries == 256 && v.n_classes == 256 - 26 && v.class_map['a'] == v.class_map['A']);
     exercise_flat (flat);
     acm_flat_release (flat);
-    CHECK (acm_flatten_classes (m, 4, &flat) == ACM_GPU_E_ARG);
+    CHECK (acm_flatten_classes (m, 8, &flat) == ACM_GPU_E_ARG);
+    acm_release (m);
+    free (letters);
+  }
+  { /* comparator classes of 4-byte symbols: those of the dictionary's own symbols */
+    size_t arg;
+    unsigned char *letters;
+    ACMachine *m = build (4, &arg, 300, 0, &letters, casecmp32);
+    ACMFlat *flat = NULL;
+    CHECK (acm_flatten_classes (m, 4, &flat) == ACM_GPU_OK);
+    ACMFlatView v;
+    ACMFlatInfo fi;
+    acm_flat_view (flat, &v);
+    acm_flat_info (flat, &fi);
+    CHECK (v.keys32 && v.keys32_class && v.class_rep32 && v.n_keys32 >= v.n_classes && v.n_classes >= 26 && fi.sym_bytes == 4);
+    for (uint32_t i = 0; i < v.n_keys32; i++)
+      CHECK (v.keys32_class[i] >= 1 && v.keys32_class[i] <= v.n_classes && (i == 0 || v.keys32[i - 1] < v.keys32[i]));
+    for (uint32_t e = 0; e < fi.n_edges; e++)
+      CHECK (v.edge_sym[e] >= 1 && v.edge_sym[e] <= v.n_classes);
+    CHECK (acm_flat_blob_bytes (flat) > 0);
+    void *blob = malloc (acm_flat_blob_bytes (flat));
+    CHECK (acm_flat_to_blob (flat, blob, acm_flat_blob_bytes (flat)) == ACM_GPU_E_ARG);
+    free (blob);
+    acm_flat_release (flat);
     acm_release (m);
     free (letters);
   }

@@ -83,3 +83,30 @@ kat_cyclic_cmp8 (const void *a, const void *b, const void *arg) {
     return 0;
   return (x + 1) % 3 == y ? -1 : 1;
 }
+
+/* the reference's alphacmp (generic_test.c:48-54) as it stands: case-insensitive order of wchar_t
+ * symbols (4 bytes here) through towlower */
+int
+kat_casecmp32 (const void *a, const void *b, const void *arg) {
+  (void)arg;
+  wint_t x = towlower (*(const wint_t *)a), y = towlower (*(const wint_t *)b);
+  return x > y ? 1 : (x < y ? -1 : 0);
+}
+
+/* not an order over 4-byte symbols: a < b < c < a */
+int
+kat_cyclic_cmp32 (const void *a, const void *b, const void *arg) {
+  (void)arg;
+  unsigned x = *(const unsigned *)a % 3u, y = *(const unsigned *)b % 3u;
+  if (x == y)
+    return 0;
+  return (x + 1) % 3 == y ? -1 : 1;
+}
+
+/* towlower beyond ASCII needs a UTF-8 locale (the reference's test calls setlocale (LC_ALL, "")) */
+#include <locale.h>
+void
+kat_setlocale_utf8 (void) {
+  if (!setlocale (LC_CTYPE, "C.UTF-8"))
+    setlocale (LC_CTYPE, "C.utf8");
+}

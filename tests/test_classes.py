@@ -76,6 +76,39 @@ def test_u16_case_insensitive_classes(kat):
     assert flat.keyword(0).tolist() == [ord(c) for c in "Été"]
 
 
+def test_u32_case_insensitive_classes_of_the_dictionary_symbols(kat):
+    """4-byte symbols (the reference's wchar_t + alphacmp, generic_test.c:48-54,73-99): the classes
+    are those of the dictionary's own symbols, 1 .. n in comparator order; a text is mapped symbol
+    by symbol with the comparator (here on the CPU, as the plan does for symbols it has not met)."""
+    kat.setlocale_utf8()
+    words = ["he", "She", "SHEERS", "his", "hi", "Hers", "ushers", "abcde", "bcd", "hers", "Été", "étÉ"]
+    kws = [np.array([ord(c) for c in w], np.uint32) for w in words]
+    m, o = pair(kat, "kat_casecmp32", 4, kws)
+    flat = m.flatten_classes()
+    assert flat.info.sym_bytes == 4 and flat.info.n_keywords == o.nb_keywords == 10 and flat.info.n_states == o.nb_states
+    keys, cls, reps = flat.keys32, flat.keys32_class, flat.class_rep32
+    assert np.all(np.diff(keys.astype(np.int64)) > 0) and cls.min() == 1 and cls.max() == flat.n_classes == reps.size
+    k2c = dict(zip(keys.tolist(), cls.tolist()))
+    assert k2c[ord("S")] == k2c[ord("s")] and k2c[ord("É")] == k2c[ord("é")] and k2c[ord("h")] != k2c[ord("i")]
+    folded = [chr(r).lower() for r in reps.tolist()]
+    assert folded == sorted(folded, key=ord)                 # comparator order = order of the lower-case code points
+    fold2c = {chr(k).lower(): c for k, c in k2c.items()}
+    text = "He found his pencil, but SHE could not find hErs; ÉTÉ, sheers! USHERS abcdE" * 30
+    classes = np.array([fold2c.get(ch.lower(), 0) for ch in text], np.uint32)
+    want = o.scan(np.array([ord(c) for c in text], np.uint32))
+    assert want.size > 300
+    assert np.array_equal(flatwalk.walk_csr(flat, classes), want)
+    assert flat.keyword(1).tolist() == [ord(c) for c in "She"]      # the dictionary's own spelling
+    with pytest.raises(binding.ACMError):
+        flat.to_bytes()                                      # no serialised form without the comparator
+    # a comparator that is no order over the dictionary's symbols is refused
+    bad = acm.Machine(4, cmp=fn_ptr(kat, "kat_cyclic_cmp32"))
+    for w in ("abc", "bca"):
+        bad.add_keyword(np.array([ord(c) for c in w], np.uint32))
+    with pytest.raises(binding.ACMError):
+        bad.flatten_classes()
+
+
 def test_default_comparator_classes_are_identity(kat):
     m = acm.Machine(1)
     for kw in (b"he", b"she", b"his", b"hers"):
@@ -96,10 +129,10 @@ def test_inconsistent_comparator_is_refused(kat):
     m2 = acm.Machine(1, cmp=fn_ptr(kat, "kat_casecmp8"))
     with pytest.raises(binding.ACMError):
         m2.flatten()
-    # 4-byte symbols cannot be enumerated
-    m4 = acm.Machine(4, cmp=fn_ptr(kat, "kat_alphacmp"))
+    # 8-byte symbols have no class path (4-byte ones do: classes of the dictionary's own symbols)
+    m8 = acm.Machine(8, cmp=fn_ptr(kat, "kat_alphacmp"))
     with pytest.raises(binding.ACMError):
-        m4.flatten_classes()
+        m8.flatten_classes()
 
 
 def test_class_machine_blob_round_trip(kat, tmp_path):

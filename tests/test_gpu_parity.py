@@ -628,6 +628,68 @@ def test_interleaved_classes_and_u16_on_the_gpu(torch_cuda, kat):
     assert np.array_equal(plan16.scan_sorted(_dev(torch_cuda, text16)[1:]), o16.scan(text16[1:]))
 
 
+GENERIC_TEST_1_KEYWORDS = ["he", "she", "sheers", "his", "hi", "hers", "ushers", "abcde", "bcd", "hers", "hen", "hen", "bcdef", "pen",
+                           "cdefg", "pen", "bcd", "abc", "abcd", "abcde", "bcde", "cde", "cd", "bc", "u", "uu"]
+GENERIC_TEST_1_TEXT = "He found his pencil, but she could not find hers (Hi! Ushers !! --abcdefgh--)"
+
+
+def _u32(s):
+    return np.array([ord(c) for c in s], np.uint32)
+
+
+def test_reference_generic_test_1_wchar_alphacmp_on_the_gpu(torch_cuda, kat, novel_bytes):
+    """The reference's flagship "any ordered alphabet" example on the GPU: generic_test.c:62-164,
+    4-byte wchar_t symbols under the case-insensitive alphacmp (:48-54).  The 2^32 symbol values
+    cannot be enumerated: the plan holds the classes of the dictionary's own symbols and
+    classifies the symbols of a text with the machine's comparator when it first meets them
+    (acm_flatten_classes with sym_bytes 4).  Records equal the oracle's with the same comparator."""
+    import ctypes as C
+    kat.setlocale_utf8()
+    cmp32 = _fn_ptr(kat, "kat_casecmp32")
+    m = acm.Machine(4, cmp=cmp32)
+    o = po.Oracle(4, po.MEYER85, cmp=cmp32)
+    for w in GENERIC_TEST_1_KEYWORDS:
+        m.add_keyword(_u32(w))
+        o.add_keyword(_u32(w))
+    assert m.nb_keywords == 21
+    plan = m.plan_classes(0)
+    text = _u32(GENERIC_TEST_1_TEXT)
+    want = o.scan(text)
+    assert want.size == 27                  # SURVEY.md Appendix C: he, u, hi, his, pen, ...
+    got = plan.scan_sorted(_dev(torch_cuda, text))
+    assert np.array_equal(got, want)
+    assert int(plan.count(_dev(torch_cuda, text)).item()) == 27
+    # MatchHolder spelling is the dictionary's, not the text's (generic_test.c output {'he'} for "He")
+    word, _ = m.keyword(int(got[0]["keyword_id"]))
+    assert word == tuple(ord(c) for c in "he") and int(got[0]["end_pos"]) == 1
+    # a long text with symbols the dictionary never saw (upper case, punctuation, Latin-1, beyond the BMP)
+    novel = np.frombuffer(novel_bytes, np.uint8).astype(np.uint32)
+    novel[::997] = 0x1F600 + (np.arange(novel[::997].size) % 50)
+    novel[5::1013] = ord("É")
+    want = o.scan(novel)
+    dev = _dev(torch_cuda, novel)
+    assert want.size > 20000
+    assert np.array_equal(plan.scan_sorted(dev), want)
+    assert np.array_equal(plan.scan_sorted(dev), want)      # nothing new to classify the second time
+    for b, e in ((1, 7), (3, 100001), (77, 12345), (novel.size - 9, novel.size)):
+        rb = max(b - 5, 0)
+        got = plan.scan_sorted(dev[rb:e], emit_from=b - rb, pos_base=rb)
+        assert np.array_equal(got, want[(want["end_pos"] >= b) & (want["end_pos"] < e)])
+    # the dictionary grows: new keywords (new symbols among them) go into the delta plan
+    for w in ("Mrs", "DALLOWAY", "Ébloui", "she said"):
+        m.add_keyword(_u32(w))
+        o.add_keyword(_u32(w))
+    plan.update(m)
+    want = o.scan(novel)
+    assert np.array_equal(plan.scan_sorted(dev), want)
+    # a comparator that is no order is refused
+    bad = acm.Machine(4, cmp=_fn_ptr(kat, "kat_cyclic_cmp32"))
+    for w in ("abc", "bca", "cab"):
+        bad.add_keyword(_u32(w))
+    with pytest.raises(acm.binding.ACMError):
+        bad.plan_classes(0)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("ACM_SOAK_SEEDS", "1"))))
 def test_incremental_updates_of_a_start_parallel_plan(torch_cuda, seed):
     """keywords added while the plan is in use (reference README.md:352-356,
