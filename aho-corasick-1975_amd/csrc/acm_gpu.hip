@@ -257,6 +257,7 @@ struct ACMPlan {
   uint32_t covered_keywords = 0; /* keywords of the machine this plan and its delta report */
   uint32_t kw_base = 0;          /* added to the keyword ids of this plan's records (delta plans) */
   uint32_t merges = 0;           /* updates that rebuilt everything */
+  ACMPlan *items_owner = nullptr; /* delta plans: the plan whose item buffer they park in (scans of the two never overlap) */
   struct Retired {
     ACMPlan *plan;
     hipEvent_t done; /* nullptr until the first scan after the retirement has recorded it */
@@ -1241,9 +1242,9 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
   }
   if (plan->blob)
     (void)hipFree (plan->blob);
-  if (plan->d_items)
+  if (plan->d_items && !plan->items_owner)
     (void)hipFree (plan->d_items);
-  if (plan->d_fill)
+  if (plan->d_fill && !plan->items_owner)
     (void)hipFree (plan->d_fill);
   if (plan->d_total)
     (void)hipFree (plan->d_total);
@@ -1505,7 +1506,11 @@ launch_csr (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
 /* (re)allocate the item buffer for segments of up to n symbols: room for one item per 256
  * symbols, at least 256 per wave; denser matches are expanded in the kernel itself */
 int
-ensure_item_buffer (ACMPlan *p, uint64_t n, uint32_t symbols_per_item = 256, uint32_t min_items = 256) {
+ensure_item_buffer (ACMPlan *user, uint64_t n, uint32_t symbols_per_item = 256, uint32_t min_items = 256) {
+  /* a delta plan parks in the buffer of the plan it belongs to: their scans run one after the
+   * other on one stream, and a fresh 140 MB buffer (with the waits it takes to set one up) for
+   * every delta made every dictionary change cost more than the delta itself */
+  ACMPlan *p = user->items_owner ? user->items_owner : user;
   const uint32_t regions = p->info.grid_blocks * (DENSE_THREADS / WAVE);
   uint64_t per = (n / symbols_per_item + regions - 1) / regions;
   per = (per + 63) / 64 * 64;
@@ -1513,25 +1518,29 @@ ensure_item_buffer (ACMPlan *p, uint64_t n, uint32_t symbols_per_item = 256, uin
     per = min_items;
   if (per > (1u << 20))
     per = 1u << 20;
-  if (p->d_items && p->regions == regions && p->region_items >= per)
-    return ACM_GPU_OK;
-  if (p->d_items || p->d_fill)
-    HIP_TRY (hipDeviceSynchronize ()); /* earlier scans (pieces of a stream) may still be parking items */
-  if (p->d_items)
-    HIP_TRY (hipFree (p->d_items));
-  if (p->d_fill)
-    HIP_TRY (hipFree (p->d_fill));
-  p->d_items = nullptr;
-  p->d_fill = nullptr;
-  if (hipMalloc (&p->d_items, (size_t)regions * per * 8) != hipSuccess)
-    return ACM_GPU_E_NOMEM;
-  if (hipMalloc (reinterpret_cast<void **> (&p->d_fill), (size_t)regions * 4) != hipSuccess)
-    return ACM_GPU_E_NOMEM;
-  HIP_TRY (hipMemset (p->d_fill, 0, (size_t)regions * 4));
-  /* the memset runs on the null stream; the scans may run on streams that do not wait for it */
-  HIP_TRY (hipDeviceSynchronize ());
-  p->regions = regions;
-  p->region_items = (uint32_t)per;
+  if (!(p->d_items && p->regions == regions && p->region_items >= per)) {
+    if (p->d_items || p->d_fill)
+      HIP_TRY (hipDeviceSynchronize ()); /* earlier scans (pieces of a stream) may still be parking items */
+    if (p->d_items)
+      HIP_TRY (hipFree (p->d_items));
+    if (p->d_fill)
+      HIP_TRY (hipFree (p->d_fill));
+    p->d_items = nullptr;
+    p->d_fill = nullptr;
+    if (hipMalloc (&p->d_items, (size_t)regions * per * 8) != hipSuccess)
+      return ACM_GPU_E_NOMEM;
+    if (hipMalloc (reinterpret_cast<void **> (&p->d_fill), (size_t)regions * 4) != hipSuccess)
+      return ACM_GPU_E_NOMEM;
+    HIP_TRY (hipMemset (p->d_fill, 0, (size_t)regions * 4));
+    /* the memset runs on the null stream; the scans may run on streams that do not wait for it */
+    HIP_TRY (hipDeviceSynchronize ());
+    p->regions = regions;
+    p->region_items = (uint32_t)per;
+  }
+  user->d_items = p->d_items;
+  user->d_fill = p->d_fill;
+  user->regions = p->regions;
+  user->region_items = p->region_items;
   return ACM_GPU_OK;
 }
 
@@ -2524,6 +2533,7 @@ acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
     fresh->cmp32 = plan->cmp32;
     fresh->cmp32_arg = plan->cmp32_arg;
     fresh->segment = plan->segment;
+    fresh->items_owner = plan;
     if (plan->delta)
       plan->retired.push_back (ACMPlan::Retired{ plan->delta, nullptr });
     plan->delta = fresh;

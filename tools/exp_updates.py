@@ -37,6 +37,35 @@ def run(name, K, sym, N=300):
           "; scan of 64 Ki symbols without a change %.4f ms" % (base * 1e3), flush=True)
 
 
+def novel():
+    """generic_test.c:166-239 on bytes: the dictionary built up from the novel while it is scanned
+    (6,966 inserts), every insert followed by acm_gpu_plan_update and a scan of 3 KB around it"""
+    import re
+    raw = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "mrs_dalloway.txt"), "rb").read()
+    t = np.frombuffer(raw, np.uint8).copy()
+    up = (t >= 65) & (t <= 90)
+    t[up] += 32
+    t[~((t >= 97) & (t <= 122))] = 32
+    m = acm.Machine(1)
+    m.add_keyword(b" the ")
+    plan = m.plan(0)
+    seen, tu, ts, th, n, kernels = {b"the"}, 0.0, 0.0, 0.0, 0, {}
+    for mt in re.finditer(rb"[a-z]+", t.tobytes()):
+        w = mt.group(0)
+        if w in seen:
+            continue
+        seen.add(w)
+        a = time.perf_counter(); m.add_keyword(b" " + w + b" "); b = time.perf_counter()
+        plan.update(m); c = time.perf_counter()
+        plan.scan_host(t[max(mt.start() - 1500, 0):mt.end() + 1500]); d = time.perf_counter()
+        th += b - a; tu += c - b; ts += d - c; n += 1
+        kernels[plan.info.kernel] = kernels.get(plan.info.kernel, 0) + 1
+    plan.info_refresh() if hasattr(plan, "info_refresh") else None
+    print("novel replay: %d inserts; per insert: host %.1f us, plan update %.1f us, scan_host of 3 KB %.1f us; merges %d; kernel of the main plan at each insert %s" % (
+        n, th / n * 1e6, tu / n * 1e6, ts / n * 1e6, plan.describe()["merges"], kernels), flush=True)
+
+
+novel()
 run("bytes, 1k keywords", 1000, 1)
 run("uint32, 10k keywords", 10000, 4)
 if len(sys.argv) > 1 and sys.argv[1] == "big":
