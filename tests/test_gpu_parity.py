@@ -417,6 +417,55 @@ def _gloo_gpu_worker(rank, world, port, n, K, out_path):
     dist.destroy_process_group()
 
 
+def _rccl_single_rank_worker(rank, port, n, K, out_path):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    kd, ko = acm.synth.keywords(K)
+    m = acm.Machine(1)
+    m.add_keywords_packed(kd, ko)
+    plan = m.plan(0)
+
+    def make_shard(read_begin, own_end):
+        return acm.synth.device_text(own_end, kd, ko)[read_begin:]
+
+    def scan_fn(text, emit_from, pos_base):
+        rec, cnt = plan.scan(text, emit_from=emit_from, pos_base=pos_base)
+        k = int(cnt.item())
+        plan.sort(rec, k)
+        return rec[:k]
+
+    got = acm.sharded.scan_sharded(scan_fn, n, m.lmax, make_shard)
+    t = torch.ones(1, device="cuda")
+    dist.all_reduce(t)                  # the timing reductions of bench.py take this road too
+    np.save(out_path, got.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_entry_point_over_rccl_single_rank(torch_cuda, tmp_path):
+    """The RCCL side of the sharded path as far as one GPU goes: the `nccl` process group, the
+    all-gather of record counts on device tensors and a device all-reduce, with world size 1
+    (peer-to-root transfers need a second GPU: the driver's 2/4/8-GPU runs)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n, K = 8 << 20, 1000
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_rccl_single_rank_worker, args=(port, n, K, out), nprocs=1, join=True)
+    got = np.frombuffer(np.load(out).tobytes(), dtype=acm.RECORD_DTYPE)
+    kd, ko = acm.synth.keywords(K)
+    o = po.Oracle(1)
+    o.add_keywords_packed(kd, ko)
+    assert np.array_equal(got, o.scan(acm.synth.text(n, kd, ko)))
+
+
 def test_sharded_scan_two_ranks_gloo_real_hip_scan(torch_cuda, tmp_path):
     """sharded.scan_sharded end to end with the product kernel as each rank's scanner: two
     processes on this one GPU over gloo (RCCL wants one GPU per rank; the N-GPU run is the
