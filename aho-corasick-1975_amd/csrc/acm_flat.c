@@ -149,6 +149,7 @@ static int
 flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint32_t class_entries, uint32_t n_classes,
               ACMFlat **out, const struct keys32_arg *k32) {
 
+  acm_internal_refresh (machine);
   acm_internal_lock (machine); /* writers are excluded while the snapshot is taken */
   const uint32_t n = acm_internal_nb_states (machine);
   ACMFlat *f = calloc (1, sizeof *f);

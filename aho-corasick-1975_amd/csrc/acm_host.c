@@ -11,6 +11,12 @@
  *     so matching and insertion interleave freely (generic_test.c:198-229);
  *   - every terminal state also records its first-insertion rank (keyword_id of acm_gpu.h) and
  *     every state its depth, which the flattener (acm_flat.c) ships to the GPU.
+ *
+ * -DACM_NMEYER_85 (the reference's -DNMEYER_85 build, aho_corasick.c:365-418,443-446; Makefile
+ * target `nmeyer85` -> libac75_amd_nmeyer85.so): no incremental maintenance; inserting only marks
+ * the failure function stale, and the next acm_match (or flatten, or acm_print) recomputes it for
+ * the whole trie by the breadth-first pass of Aho & Corasick 1975, algorithm 3.  The automaton is
+ * the same, so the flat tables and every scan are too (tests/test_nmeyer85.py).
  */
 #define _GNU_SOURCE
 #include "acm_internal.h"
@@ -60,6 +66,7 @@ struct _ac_machine {
   struct garbage *garbage; /* outgrown edge blocks: lock-free readers may still hold them */
   struct _ac_state **keywords; /* keyword_id -> terminal state (acm_get_keyword) */
   size_t keywords_cap;
+  int stale; /* ACM_NMEYER_85: failure links and output counts await the breadth-first pass */
 };
 
 void (*acm_internal_plan_dropper) (void *plan) = 0;
@@ -70,7 +77,11 @@ cmp_bytes (const void *a, const void *b, const void *arg) { /* reference :134-13
   return memcmp (a, b, *(const size_t *)arg);
 }
 const CMP_TYPE ACM_CMP_DEFAULT = cmp_bytes;
+#ifdef ACM_NMEYER_85
+const int ACM_INCREMENTAL_STRING_MATCHING = 0; /* reference :596-597 */
+#else
 const int ACM_INCREMENTAL_STRING_MATCHING = 1; /* reference :596-597 (default build) */
+#endif
 
 /* ------------------------------------------------------------------ internal accessors */
 uint64_t
@@ -276,6 +287,9 @@ walk_push (struct walk *w, struct _ac_state *s) {
  *   n that stops at the first node owning a c-child on each branch.
  * The walk runs on the tree as it was BEFORE any re-pointing (targets are collected first), so
  * it does not depend on container mutation order. */
+#ifdef ACM_NMEYER_85
+__attribute__ ((unused))
+#endif
 static void
 link_failure_of_new_leaf (struct _ac_state *n, struct _ac_state *leaf) {
   if (n->fail)
@@ -309,6 +323,46 @@ link_failure_of_new_leaf (struct _ac_state *n, struct _ac_state *leaf) {
     free (hits.v);
   }
   inv_add (leaf->fail, leaf);
+}
+
+/* AC-75, algorithm 3 (reference :365-418): failure links and output counts of the whole trie in
+ * one breadth-first pass -- f of a depth-1 state is the root; f(child of u on a) = the first goto
+ * on a met down u's failure chain, else the root; nb_outputs(s) = [s terminal] + nb_outputs(f(s)).
+ * Does nothing in the default (Meyer-85) build, whose links are always current. */
+void
+acm_internal_refresh (ACMachine *m) {
+#ifdef ACM_NMEYER_85
+  if (!LOAD (&m->stale))
+    return;
+  ACM_REQUIRE (mtx_lock (&m->lock) == thrd_success, "");
+  if (m->stale) {
+    struct _ac_state **queue = malloc ((size_t)m->nb_states * sizeof *queue);
+    ACM_REQUIRE (queue, "Out of memory.");
+    size_t head = 0, tail = 0;
+    queue[tail++] = m->root;
+    while (head < tail) {
+      struct _ac_state *u = queue[head++];
+      for (uint32_t i = 0; i < ACM_NKIDS (u); i++) {
+        struct _ac_state *c = ACM_KID (u, i), *target = m->root;
+        for (const struct _ac_state *v = u->fail; v; v = v->fail) {
+          struct _ac_state *t = child_find (v, c->letter, 0);
+          if (t) {
+            target = t;
+            break;
+          }
+        }
+        STORE (&c->fail, target);
+        STORE (&c->nb_outputs, (uint32_t)(c->terminal ? 1 : 0) + target->nb_outputs);
+        queue[tail++] = c;
+      }
+    }
+    free (queue);
+    STORE (&m->stale, 0);
+  }
+  ACM_REQUIRE (mtx_unlock (&m->lock) == thrd_success, "");
+#else
+  (void)m;
+#endif
 }
 
 /* ------------------------------------------------------------------ public API */
@@ -379,7 +433,12 @@ acm_insert_letter_of_keyword (ACState **state, void *letter) {
     k->parent = n;
     k->letter = letter;
     k->depth = n->depth + 1;
+#ifdef ACM_NMEYER_85
+    k->fail = m->root; /* provisional (only the root may have none): acm_internal_refresh sets it */
+    m->stale = 1;
+#else
     link_failure_of_new_leaf (n, k);
+#endif
     child_insert (n, at, k);
     m->generation++;
   }
@@ -411,6 +470,12 @@ acm_insert_end_of_keyword (ACState **state, void *value, void (*dtor) (void *)) 
     /* the terminal mark first, then the counts: a reader that sees a count sees the terminal
      * states acm_get_match will look for down the failure chain */
     STORE (&n->terminal, 1);
+#ifdef ACM_NMEYER_85
+    m->stale = 1; /* the output counts come with the next breadth-first pass */
+    if (0) {
+#else
+    {
+#endif
     /* one more keyword ends at n and at every state that has n as a suffix, i.e. the whole
      * failure subtree of n (reference enter_output, :330-338) */
     struct walk todo = { 0 };
@@ -422,6 +487,7 @@ acm_insert_end_of_keyword (ACState **state, void *value, void (*dtor) (void *)) 
         walk_push (&todo, x->inv[i]);
     }
     free (todo.v);
+    }
     m->generation++;
   }
   *state = m->root;
@@ -432,6 +498,9 @@ acm_insert_end_of_keyword (ACState **state, void *value, void (*dtor) (void *)) 
 size_t
 acm_match (const ACState **state, const void *letter) {
   ACM_REQUIRE (state && *state && letter, "Invalid null state or letter.");
+#ifdef ACM_NMEYER_85
+  acm_internal_refresh ((*state)->machine); /* reference :443-446 */
+#endif
   return LOAD (&(*state = automaton_step (*state, letter))->nb_outputs);
 }
 
@@ -585,6 +654,7 @@ print_subtree (const struct _ac_state *s, FILE *out, int *col, int indent, PRINT
 void
 acm_print (ACMachine *machine, FILE *stream, PRINT_TYPE printer) {
   ACM_REQUIRE (machine, "Invalid null machine.");
+  acm_internal_refresh (machine); /* reference :589: also with a null stream */
   if (!stream)
     return;
   int col = 0;

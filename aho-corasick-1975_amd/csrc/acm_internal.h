@@ -51,6 +51,9 @@ uint32_t acm_internal_nb_states (const ACMachine *m);
 /* 0 if the machine uses ACM_CMP_DEFAULT over 1, 2 or 4 byte symbols, else ACM_GPU_E_INELIGIBLE */
 int acm_internal_symbol_bytes (const ACMachine *m, uint32_t *sym_bytes);
 void acm_internal_comparator (const ACMachine *m, CMP_TYPE *cmp, void **cmp_arg);
+/* ACM_NMEYER_85 builds: brings failure links and output counts up to date (no-op otherwise);
+ * takes the machine lock itself */
+void acm_internal_refresh (ACMachine *m);
 void acm_internal_lock (ACMachine *m);
 void acm_internal_unlock (ACMachine *m);
 /* acm_get_keyword for callers that already hold the machine lock */

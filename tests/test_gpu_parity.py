@@ -77,6 +77,51 @@ def test_acm_scan_on_machine_follows_dictionary_updates(torch_cuda):
     assert np.array_equal(m.scan_host(text), o.scan(text))
 
 
+@pytest.mark.parametrize("K", [300, 20000])
+def test_plan_with_delta_scans_counts_and_streams(torch_cuda, K):
+    """acm_gpu_plan_update on a dense plan (300 keywords) and on a 4-gram plan (20,000): the keywords
+    added afterwards live in a delta plan; whole scans, count-only scans, shards with warm-up and a
+    stream fed in pieces all report the union, with the machine's keyword ids."""
+    kd, ko = acm.synth.keywords(K + 150)
+    m, o = build_pair_packed(kd[:ko[K]], ko[:K + 1], variant=po.MEYER85)
+    plan = m.plan(0)
+    base_kernel = plan.info.kernel
+    text = acm.synth.text(1 << 20, kd, ko)
+    dev = _dev(torch_cuda, text)
+    assert np.array_equal(plan.scan_sorted(dev), o.scan(text))
+    for k in range(K, K + 150):
+        w = kd[ko[k]:ko[k + 1]]
+        m.add_keyword(w)
+        o.add_keyword(w)
+        if k % 50 == 49 or k == K:
+            plan.update(m)
+            assert plan.info.kernel == base_kernel and plan.info.merges == 0 and plan.info.delta_keywords == k + 1 - K
+            want = o.scan(text)
+            assert np.array_equal(plan.scan_sorted(dev), want)
+            assert int(plan.count(dev).item()) == want.size
+    want = o.scan(text)
+    assert int(np.sum(want["keyword_id"] >= K)) > 10          # the new keywords do match
+    for b, e in ((5, 77), (4103, 4103 + 50000), (text.size - 33, text.size)):
+        rb = max(b - (m.lmax - 1), 0)
+        got = plan.scan_sorted(dev[rb:e], emit_from=b - rb, pos_base=rb)
+        assert np.array_equal(got, want[(want["end_pos"] >= b) & (want["end_pos"] < e)])
+    st = plan.stream(max_piece_symbols=100000, record_capacity=want.size + 16)
+    for off in range(0, text.size, 77777):
+        st.feed(text[off:off + 77777])
+    assert np.array_equal(st.finish(), want)
+    st.close()
+    assert np.array_equal(plan.scan_host(text[:50000]), want[want["end_pos"] < 50000])
+    # enough new keywords and the next update merges everything into one plan again
+    kd2, ko2 = acm.synth.keywords(K + 150 + max(256, K // 8) + 10)
+    for k in range(K + 150, len(ko2) - 1):
+        w = kd2[ko2[k]:ko2[k + 1]]
+        m.add_keyword(w)
+        o.add_keyword(w)
+    plan.update(m)
+    assert plan.info.merges == 1 and plan.info.delta_keywords == 0
+    assert np.array_equal(plan.scan_sorted(dev), o.scan(text))
+
+
 def _novel_words(novel_bytes):
     """generic_test.c:191-197: letters in lower case, everything else a blank"""
     t = np.frombuffer(novel_bytes, np.uint8).copy()
