@@ -8,6 +8,21 @@ lane_id () {
   return __builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u));
 }
 
+/* number of set bits of a ballot below this lane: two v_mbcnt (the and-and-popcount the compiler
+ * makes of `popcount (m & ((1 << lane) - 1))` is four instructions, at every queue push) */
+__device__ __forceinline__ uint32_t
+rank_below (uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi ((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo ((uint32_t)m, 0u));
+}
+
+/* (a << s) | b in one instruction */
+__device__ __forceinline__ uint32_t
+lshl_or (uint32_t a, uint32_t s, uint32_t b) {
+  uint32_t r;
+  asm ("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(s), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ uint32_t
 uniform (uint32_t v) { /* tells the compiler the value is the same in every lane */
   return __builtin_amdgcn_readfirstlane (v);
@@ -202,7 +217,7 @@ queue_push (const EmitCtx &E, uint2 *queue, uint32_t &qn, bool hit, uint32_t pos
   const uint64_t m = __ballot (hit);
   if (m) {
     if (hit)
-      queue[qn + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos, word);
+      queue[qn + rank_below (m)] = make_uint2 (pos, word);
     qn = uniform (qn + (uint32_t)__popcll (m));
     if (qn > QCAP - WAVE) {
       queue_drain<CONT, COUNT_ONLY, PARK_ONLY> (E, queue, qn, sp, lane);

@@ -180,7 +180,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       const uint64_t m = __ballot (pass);
       if (m) {
         if (pass)
-          q2[qn2 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pend_item[0].x + 3, pend_rec[0].y | WI_REPORTED);
+          q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 3, pend_rec[0].y | WI_REPORTED);
         qn2 = uniform (qn2 + (uint32_t)__popcll (m));
         while (qn2 >= WAVE)
           walk_batch (WAVE);
@@ -292,7 +292,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           const uint64_t m = __ballot (push);
           if (m) {
             if (push)
-              q1[qn1 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (p, win[j]);
+              q1[qn1 + rank_below (m)] = make_uint2 (p, win[j]);
             qn1 = uniform (qn1 + (uint32_t)__popcll (m));
             if (qn1 >= WAVE) {
               consume_oldest ();
@@ -321,7 +321,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
               const uint64_t m = __ballot (push);
               if (m) {
                 if (push)
-                  q3[qn3 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (p, key[j]);
+                  q3[qn3 + rank_below (m)] = make_uint2 (p, key[j]);
                 qn3 = uniform (qn3 + (uint32_t)__popcll (m));
                 if (qn3 >= WAVE)
                   short_batch (WAVE);
@@ -379,7 +379,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           const uint64_t m = __ballot (nib != 0);
           if (m) {
             if (nib)
-              q3[qn3 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos0 + 8 * h + j, ix3[j] | (nib << 20));
+              q3[qn3 + rank_below (m)] = make_uint2 (pos0 + 8 * h + j, ix3[j] | (nib << 20));
             qn3 = uniform (qn3 + (uint32_t)__popcll (m));
             if (qn3 >= WAVE)
               short_batch (WAVE);
@@ -392,7 +392,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
         const uint64_t m = __ballot (push);
         if (m) {
           if (push)
-            q1[qn1 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos0 + 8 * h + j, ix[j] | (c[8 * h + j + 4] << 20));
+            q1[qn1 + rank_below (m)] = make_uint2 (pos0 + 8 * h + j, lshl_or (c[8 * h + j + 4], 20u, ix[j]));
           qn1 = uniform (qn1 + (uint32_t)__popcll (m));
           if (qn1 >= WAVE) {
             DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)

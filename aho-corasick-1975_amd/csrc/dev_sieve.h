@@ -112,7 +112,7 @@ scan_sieve_kernel (SieveK S, EmitCtx E, Launch A, const unsigned char *__restric
       const uint64_t m = __ballot (pass);
       if (m) {
         if (pass)
-          q2[qn2 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pend_pos[0] + 3, pend_a[0].y | WI_REPORTED);
+          q2[qn2 + rank_below (m)] = make_uint2 (pend_pos[0] + 3, pend_a[0].y | WI_REPORTED);
         qn2 = uniform (qn2 + (uint32_t)__popcll (m));
         while (qn2 >= WAVE)
           walk_batch (WAVE);
@@ -189,7 +189,7 @@ scan_sieve_kernel (SieveK S, EmitCtx E, Launch A, const unsigned char *__restric
       if (mask) {
         const uint32_t b = (uint32_t)__builtin_ctz (mask);
         mask &= mask - 1u;
-        q1[qn1 + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (pos0 + b, 0u);
+        q1[qn1 + rank_below (m)] = make_uint2 (pos0 + b, 0u);
       }
       qn1 = uniform (qn1 + (uint32_t)__popcll (m));
       if (qn1 >= WAVE) {

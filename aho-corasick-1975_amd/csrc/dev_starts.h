@@ -187,7 +187,7 @@ emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t la
       hn = 0;
     }
     if (hit)
-      hits[hn + (uint32_t)__popcll (m & ((1ull << lane) - 1))] = make_uint2 (p, st);
+      hits[hn + rank_below (m)] = make_uint2 (p, st);
     tally = hn + total;
   }
 }
@@ -250,7 +250,7 @@ walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue
   const bool go = nx != NONE;
   const uint64_t m = __ballot (go);
   if (go)
-    queue[base + (uint32_t)__popcll (m & ((1ull << lane) - 1))] = make_uint2 (p + 1, nx | (GRAM ? WI_RECORD : 0u));
+    queue[base + rank_below (m)] = make_uint2 (p + 1, nx | (GRAM ? WI_RECORD : 0u));
   const uint32_t fill = base + (uint32_t)__popcll (m);
   if (COUNT_ONLY)
     return ((unsigned long long)fill << 32) | (uint32_t)counted;
@@ -393,7 +393,7 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
     const uint64_t m = __ballot (deep);
     if (m) {
       if (deep)
-        queue[qn + __popcll (m & ((1ull << lane) - 1))] = make_uint2 (P.pos, P.child & ST_STATE);
+        queue[qn + rank_below (m)] = make_uint2 (P.pos, P.child & ST_STATE);
       qn = uniform (qn + (uint32_t)__popcll (m));
       while (qn >= WAVE) {
         DIAG (const unsigned long long d_c0 = __builtin_readcyclecounter ();)
