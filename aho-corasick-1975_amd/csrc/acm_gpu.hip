@@ -106,6 +106,12 @@ struct EmitCtx {
    * (position, 4, kw4[rank]) -- a 360 KB table that stays in L2 instead of the 16-byte output
    * records of all 508,339 states (config 3: 26 of 27 M hits per GiB are keywords of 4 symbols) */
   const uint32_t *kw4;
+  /* dense kernel, continuation mode: per rowless state s (index s - chain_base) what lies below
+   * it when that is ONE path to a leaf: { r | depth (hotfail (s)) << 4, leaf state t, the r <= 8
+   * symbols of the path }; r = 0: no such record (walk_continuation goes step by step), r = 15:
+   * s is a leaf.  NULL: none. */
+  const uint4 *chain;
+  uint32_t chain_base;
 };
 constexpr uint32_t HIT_LEN4 = 0x80000000u;
 
@@ -194,6 +200,7 @@ struct ACMPlan {
   const uint4 *d_oinfo = nullptr;
   const uint32_t *d_kw4 = nullptr;
   const uint16_t *d_cont_dh = nullptr;
+  const uint4 *d_chain = nullptr; /* EmitCtx::chain */
   /* sparse kernel (2- and 4-byte symbols) */
   SparseK SK{};
   StartsK TK{};
@@ -717,6 +724,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const size_t o_dense = blob_reserve (cur, dense_bytes + 16);
   const size_t o_contdh = blob_reserve (cur, cont ? (size_t)n * 2 : 0);
   const size_t o_wrows = blob_reserve (cur, cont ? (size_t)n * fi.width * 4 : 0);
+  const size_t o_chain = blob_reserve (cur, cont ? (size_t)(n - HD) * 16 + 16 : 0);
   const size_t o_dstart = blob_reserve (cur, ((size_t)fi.lmax + 2) * 4);
   const uint32_t rows_lds = dense ? ((HD * rowbytes + 15) & ~15u) : 0;
   const uint32_t image_bytes = dense ? ((rows_lds + (cont ? (n - HD) * 2 : 0) + 15) & ~15u) : 0;
@@ -907,6 +915,38 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
       for (uint32_t s = 0; s < n; s++)
         cdh[s] = (uint16_t)fv.depth[hotfail[s]];
       memcpy (&host[o_image + rows_lds], hotfail.data () + HD, (size_t)(n - HD) * 2);
+      /* Chain records (EmitCtx::chain).  A continuation item says: walk on from rowless state s and
+       * report what is longer than j + depth (hotfail (s)) after j more symbols.  When f(s) has a
+       * row (hotfail (s) = f(s)), every failure transition out of the trie below s lands no deeper
+       * than that bound, so the walk can only ever report along the goto path; and when that path
+       * is a single chain of r <= 8 symbols to a leaf t with no keyword ending on the way, the
+       * whole walk is one comparison of the next r text bytes: 2 independent loads instead of 4-8
+       * dependent ones in expand_items_once_kernel. */
+      uint32_t *ch = reinterpret_cast<uint32_t *> (&host[o_chain]);
+      for (uint32_t s0 = HD; s0 < n; s0++) {
+        uint32_t *r = ch + 4 * (size_t)(s0 - HD);
+        const uint32_t dh = fv.depth[hotfail[s0]];
+        if (fv.fail[s0] >= HD || dh >= 4000)
+          continue;
+        uint64_t syms = 0;
+        uint32_t len = 0, st = s0;
+        bool ok = true;
+        while (fv.row_ptr[st + 1] > fv.row_ptr[st]) { /* until a leaf */
+          if (fv.row_ptr[st + 1] - fv.row_ptr[st] != 1 || len == 8 || (st != s0 && fv.term_kw[st] != NONE)) {
+            ok = false;
+            break;
+          }
+          syms |= (uint64_t)(fv.edge_sym[fv.row_ptr[st]] & 0xFFu) << (8 * len);
+          st = fv.edge_next[fv.row_ptr[st]];
+          len++;
+        }
+        if (!ok)
+          continue;
+        r[0] = (len ? len : 15u) | (dh << 4);
+        r[1] = st;
+        r[2] = (uint32_t)syms;
+        r[3] = (uint32_t)(syms >> 32);
+      }
     }
   }
   if (hipMalloc (&p->blob, cur) != hipSuccess) {
@@ -940,6 +980,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     p->d_dense = b + o_dense;
     p->d_lds_image = b + o_image;
     p->d_cont_dh = cont ? reinterpret_cast<const uint16_t *> (b + o_contdh) : nullptr;
+    p->d_chain = cont ? reinterpret_cast<const uint4 *> (b + o_chain) : nullptr;
     p->d_wrows = cont ? reinterpret_cast<const uint32_t *> (b + o_wrows) : nullptr;
     p->lds_image_bytes = image_bytes;
     DenseK &K = p->K;
@@ -2036,6 +2077,8 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   E.chunk = p->chunk;
   E.n_states = p->finfo.n_states;
   E.kw4 = p->d_kw4;
+  E.chain = p->d_chain;
+  E.chain_base = p->K.HD;
   E.error = p->d_total ? reinterpret_cast<unsigned int *> (p->d_total) + 3 : nullptr;
 
   /* segments of at most SEGMENT symbols; each restarts from the root `halo` symbols early

@@ -93,8 +93,34 @@ __device__ __forceinline__ ContResult
 walk_continuation (const EmitCtx &E, uint2 it, uint64_t o) {
   ContResult r = { 0, 0, 0, 0, make_uint4 (0, 0, 0, 0) };
   const uint32_t pos = it.x, st = it.y & IT_STATE;
-  const uint32_t dh = E.cont_dh[st];
   const uint32_t ce = item_chunk_end (E, it);
+  if (E.chain && st >= E.chain_base && pos + 9 <= E.n) {
+    /* all that lies below st is one path of len symbols to a leaf t (chain record, acm_gpu.hip):
+     * what the walk below would find is t's keyword len symbols on, or nothing */
+    const uint4 c = E.chain[st - E.chain_base];
+    const uint32_t len = c.x & 15u;
+    if (len) {
+      uint64_t have; /* the next 8 text bytes (any alignment) */
+      __builtin_memcpy (&have, E.text + pos + 1, 8);
+      const uint64_t want = ((uint64_t)c.w << 32) | c.z;
+      const uint32_t p = pos + len;
+      if (len != 15u && ((want ^ have) << (64u - 8u * len)) == 0 && p >= E.emit_from) {
+        const uint32_t past = p + 1 > ce ? p + 1 - ce : 0, jd = len + (c.x >> 4);
+        const uint32_t bound = jd > past ? jd : past;
+        const uint4 oi = E.oinfo[c.y];
+        const uint32_t cnt = put_outputs<WRITE> (E, oi, p, bound, o);
+        if (cnt) {
+          r.ev_pos = p;
+          r.ev_oi = oi;
+          r.ev_bound = bound;
+          r.events = 1;
+          r.cnt = cnt;
+        }
+      }
+      return r;
+    }
+  }
+  const uint32_t dh = E.cont_dh[st];
   uint32_t s2 = st;
   uint32_t byte = pos + 1 < E.n ? E.text[pos + 1] : 0;
   for (uint32_t j = 1; pos + j < E.n; j++) {
