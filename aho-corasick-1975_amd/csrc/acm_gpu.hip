@@ -1433,7 +1433,8 @@ set_tile_pool (ACMPlan *p, Launch &a, uint32_t waves) {
 /* records of the hits parked by `regions_used` waves of the start-parallel / 4-gram kernels */
 void
 launch_expand_hits (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, hipStream_t st) {
-  hipLaunchKernelGGL ((expand_hits_kernel<1024, 8>), dim3 ((regions_used + 7) / 8), dim3 (1024), 0, st, E,
+  /* 1024 threads per 16 regions (config 3, 4 GiB: 1.10 ms; 8, 4, 2 regions or smaller blocks: 1.25-1.33) */
+  hipLaunchKernelGGL ((expand_hits_kernel<1024, 16>), dim3 ((regions_used + 15) / 16), dim3 (1024), 0, st, E,
                       static_cast<const uint2 *> (p->d_items), p->region_items, p->d_fill, regions_used);
 }
 
