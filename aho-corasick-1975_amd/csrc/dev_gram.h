@@ -125,18 +125,22 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   unsigned long long counted = 0;
   /* batches of the first queue whose records are in flight: a pipeline of GRAM_DEPTH batches
    * (the gather of a batch has the time it takes the scan to fill that many more before it is
-   * looked at: one batch ahead left the L2 / MALL latency exposed) */
-  constexpr int GRAM_DEPTH = WIDE ? 3 : 4; /* narrow: one more step, the record comes in two dependent lookups */
+   * looked at: one batch ahead left the L2 / MALL latency exposed).  Narrow alphabets: the record
+   * comes in two dependent lookups, one per pipeline step -- slot 2 holds {prefix count asked for,
+   * rank inside the word | NEED}, slots 1 and 0 {entry, state}.  A value is only ever copied one
+   * step AFTER its load was issued: a copy in the same step (the load landing in a temporary and
+   * moved to its slot at once) is an s_waitcnt vmcnt(0) per batch, latency of the gather and of
+   * the prefetched text included. */
+  constexpr int GRAM_DEPTH = 3;
   DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_items = 0, d_b1 = 0, d_cons = 0, d_tiles = 0;)
-  uint2 pend_item[GRAM_DEPTH], pend_rec[GRAM_DEPTH];
+  uint2 pend_item[GRAM_DEPTH];
+  uint32_t pend_rx[GRAM_DEPTH], pend_ry[GRAM_DEPTH]; /* the record's two words, apart: a 64-bit register pair half in flight pins both */
   uint32_t pend_n[GRAM_DEPTH]; /* wave-uniform: items in each pending batch, [0] the oldest */
-  /* narrow, newest batch only: the prefix count asked for, the rank inside the word | NEED */
-  uint32_t pend_pre = 0, pend_in = 0;
   constexpr uint32_t PEND_NEED = 0x80000000u;
 #pragma unroll
   for (int d = 0; d < GRAM_DEPTH; d++) {
     pend_item[d] = make_uint2 (0, 0);
-    pend_rec[d] = make_uint2 (0, 0);
+    pend_rx[d] = pend_ry[d] = 0;
     pend_n[d] = 0;
   }
 
@@ -160,7 +164,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       if (WIDE) {
         /* the slot that came back is the first of the probe sequence: a hit, an empty slot (the
          * Bloom bit was a false positive), or somebody else's window -- then probe on (rare) */
-        uint2 e = pend_rec[0];
+        uint2 e = make_uint2 (pend_rx[0], pend_ry[0]);
         uint32_t slot = (pend_item[0].y * WIDE_H2) >> (32 - K.wtab_log2);
         while (valid && (e.y & ST_STATE) != 0 && e.x != pend_item[0].y) {
           slot = (slot + 1) & ((1u << K.wtab_log2) - 1);
@@ -168,36 +172,49 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
         }
         valid = valid && (e.y & ST_STATE) != 0;
         /* same shape as the exact table's record: terminal bit 31, "goes on" as bit 0 of the mask */
-        pend_rec[0] = make_uint2 ((e.y & WT_TERM) | ((e.y & WT_KIDS) ? 1u : 0u), e.y & ST_STATE);
+        pend_rx[0] = (e.y & WT_TERM) | ((e.y & WT_KIDS) ? 1u : 0u);
+        pend_ry[0] = e.y & ST_STATE;
       }
       /* a keyword of length 4 ends here: reported at once, its record needs nothing but the
        * state id (the trie records of the 508,339 states are 16 MB of HBM: not worth a visit) */
-      const bool term = valid && (pend_rec[0].x >> 31) && pend_item[0].x + 3 >= E.emit_from;
-      emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, (pend_rec[0].y - K.d4_begin) | HIT_LEN4, lane, hits, counted);
+      const bool term = valid && (pend_rx[0] >> 31) && pend_item[0].x + 3 >= E.emit_from;
+      emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, (pend_ry[0] - K.d4_begin) | HIT_LEN4, lane, hits, counted);
       if (!COUNT_ONLY)
         counted = uniform ((uint32_t)counted);
-      const bool pass = valid && ((pend_rec[0].x >> (WIDE ? 0u : c4)) & 1u);
+      const bool pass = valid && ((pend_rx[0] >> (WIDE ? 0u : c4)) & 1u);
       const uint64_t m = __ballot (pass);
       if (m) {
         if (pass)
-          q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 3, pend_rec[0].y | WI_REPORTED);
+          q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 3, pend_ry[0] | WI_REPORTED);
         qn2 = uniform (qn2 + (uint32_t)__popcll (m));
         while (qn2 >= WAVE)
           walk_batch (WAVE);
       }
     }
-#pragma unroll
-    for (int d = 0; d + 1 < GRAM_DEPTH; d++) {
-      pend_item[d] = pend_item[d + 1];
-      pend_rec[d] = pend_rec[d + 1];
-      pend_n[d] = pend_n[d + 1];
+    pend_item[0] = pend_item[1];
+    pend_rx[0] = pend_rx[1];
+    pend_ry[0] = pend_ry[1];
+    pend_n[0] = pend_n[1];
+    pend_item[1] = pend_item[2];
+    pend_n[1] = pend_n[2];
+    pend_n[2] = 0;
+    if (WIDE)
+    {
+      pend_rx[1] = pend_rx[2];
+      pend_ry[1] = pend_ry[2];
     }
-    pend_n[GRAM_DEPTH - 1] = 0;
-    if (!WIDE && pend_n[GRAM_DEPTH - 2]) {
-      /* the batch that has just left the newest slot: its prefix counts are here, now the entries */
-      const uint32_t rank = pend_pre + (pend_in & ~PEND_NEED);
-      const uint32_t ent = (pend_in & PEND_NEED) ? K.g4entry[rank] : 0u;
-      pend_rec[GRAM_DEPTH - 2] = make_uint2 (ent, K.d4_begin + rank);
+    else {
+      /* the batch that has just left the newest slot: its prefix counts are here, now the entries
+       * (issued after the copies above, straight into the slot they will be read from) */
+      asm volatile ("" : "+v"(pend_rx[0]), "+v"(pend_ry[0]), "+v"(pend_item[0].x), "+v"(pend_item[0].y),
+                    "+v"(pend_item[1].x), "+v"(pend_item[1].y));
+      __builtin_amdgcn_sched_barrier (0);
+      const uint32_t rank = pend_rx[2] + (pend_ry[2] & ~PEND_NEED);
+      uint32_t ent = 0;
+      if (pend_n[1] && (pend_ry[2] & PEND_NEED))
+        ent = K.g4entry[rank];
+      pend_rx[1] = ent;
+      pend_ry[1] = K.d4_begin + rank;
     }
   };
   /* takes the newest n items of the first queue and sends for their records (the last pipeline
@@ -206,7 +223,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     qn1 -= n_items;
     pend_item[GRAM_DEPTH - 1] = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
     if (WIDE)
-      pend_rec[GRAM_DEPTH - 1] = K.wtab[(pend_item[GRAM_DEPTH - 1].y * WIDE_H2) >> (32 - K.wtab_log2)];
+    {
+      const uint2 e = K.wtab[(pend_item[GRAM_DEPTH - 1].y * WIDE_H2) >> (32 - K.wtab_log2)];
+      pend_rx[GRAM_DEPTH - 1] = e.x;
+      pend_ry[GRAM_DEPTH - 1] = e.y;
+    }
     else {
       const uint32_t idx = pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu;
       bool need = lane < n_items;
@@ -223,9 +244,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       }
       /* (a lane that needs nothing asks for nothing: a gather costs by the line) */
       const uint32_t word = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
-      pend_in = __popc (word & ((1u << (idx & 31u)) - 1u)) | (need ? PEND_NEED : 0u);
-      pend_pre = need ? K.g4prefix[idx >> 5] : 0u;
-      pend_rec[GRAM_DEPTH - 1] = make_uint2 (0, 0);
+      uint32_t pre = 0;
+      if (need)
+        pre = K.g4prefix[idx >> 5];
+      pend_rx[GRAM_DEPTH - 1] = pre;
+      pend_ry[GRAM_DEPTH - 1] = __popc (word & ((1u << (idx & 31u)) - 1u)) | (need ? PEND_NEED : 0u);
     }
     pend_n[GRAM_DEPTH - 1] = n_items;
   };
