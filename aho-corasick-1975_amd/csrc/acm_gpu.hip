@@ -555,13 +555,13 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     if (G.bloom) {
       auto set = [&] (uint32_t slot) { G.bloom[slot >> 5] |= 1u << (slot & 31); };
       if (fv.term_kw[st] != NONE) {
-        set (gram_bloom_slot (idx, G.bloomT_bits, 0));
-        set (gram_bloom_slot (idx, G.bloomT_bits, 1));
+        set (gram_bloom_slot (gram_bloom_hash (idx, 0), G.bloomT_bits));
+        set (gram_bloom_slot (gram_bloom_hash (idx, 1), G.bloomT_bits));
       }
       for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++) {
-        const uint32_t key5 = idx * G.W + (fv.edge_sym[e] - G.lo);
-        set (G.bloomT_bits + gram_bloom_slot (key5, G.bloom5_bits, 0));
-        set (G.bloomT_bits + gram_bloom_slot (key5, G.bloom5_bits, 1));
+        const uint32_t c5 = fv.edge_sym[e] - G.lo;
+        set (G.bloomT_bits + gram_bloom_slot (gram_bloom_hash5 (idx, c5, 0), G.bloom5_bits));
+        set (G.bloomT_bits + gram_bloom_slot (gram_bloom_hash5 (idx, c5, 1), G.bloom5_bits));
       }
     }
   }

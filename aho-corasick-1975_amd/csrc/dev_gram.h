@@ -69,11 +69,37 @@ struct GramK {
 };
 
 constexpr uint32_t WIDE_H1 = 0x9E3779B1u, WIDE_H2 = 0x85EBCA6Bu; /* multiplicative hashes: Bloom bits, table slots */
-/* the two bit positions of a key in a Bloom filter of m bits (m < 2^24; host and device alike) */
+/* The two bit positions of a key in a Bloom filter of m bits (m a multiple of 32, below 2^21;
+ * host and device alike), in full-rate 24-bit multiplies only (v_mul_lo_u32 / v_mul_hi_u32 hold
+ * the SIMD four times as long, and a batch of the kernel's second stage asks for four positions):
+ * h = key x odd constant (24 x 24 bits, low word); its low 24 bits scaled to the filter's words
+ * pick the word, its low 5 bits the bit. */
+constexpr uint32_t BLOOM_C1 = 0x9E3779u, BLOOM_C2 = 0x85EBCBu, BLOOM_D1 = 0xC2B2AFu, BLOOM_D2 = 0x27D4EBu;
+/* key = a 4-gram index; with a 5th symbol's class c5 (5-gram filter) the same product plus c5 x constant */
 __host__ __device__ __forceinline__ uint32_t
-gram_bloom_slot (uint32_t key, uint32_t m, int which) {
-  const uint32_t h = which ? (key * WIDE_H2) ^ ((key * WIDE_H1) >> 15) : key * WIDE_H1;
-  return (uint32_t)(((uint64_t)h * m) >> 32);
+gram_bloom_hash (uint32_t idx, int which) {
+  return (idx & 0xFFFFFFu) * (which ? BLOOM_C2 : BLOOM_C1);
+}
+__host__ __device__ __forceinline__ uint32_t
+gram_bloom_hash5 (uint32_t idx, uint32_t c5, int which) {
+  return gram_bloom_hash (idx, which) + c5 * (which ? BLOOM_D2 : BLOOM_D1);
+}
+__host__ __forceinline__ uint32_t
+gram_bloom_slot (uint32_t h, uint32_t m) {
+  const uint32_t word = (uint32_t)(((uint64_t)(h & 0xFFFFFFu) * ((m / 32) << 8)) >> 32);
+  return word * 32 + (h & 31u);
+}
+__device__ __forceinline__ uint32_t
+mul_hi_u24 (uint32_t a, uint32_t b) { /* bits 32..47 of the product of the operands' low 24 bits */
+  uint32_t r;
+  asm ("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t
+mad_u24 (uint32_t a, uint32_t b, uint32_t c) { /* (the compiler turns the C expression into a 64-bit mad when it likes) */
+  uint32_t r;
+  asm ("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
 }
 constexpr uint32_t WT_TERM = 0x80000000u, WT_KIDS = 0x40000000u;
 
@@ -232,15 +258,18 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       const uint32_t idx = pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu;
       bool need = lane < n_items;
       if (K.bloom5_bits) {
-        auto bit = [&] (uint32_t slot) -> uint32_t {
-          const uint32_t w = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (K.bloom_off + (slot >> 5) * 4u);
-          return (w >> (slot & 31u)) & 1u;
+        /* (word scale and byte offset of the two filters: wave-uniform, in SGPRs) */
+        const uint32_t scaleT = (K.bloomT_bits / 32) << 8, scale5 = (K.bloom5_bits / 32) << 8;
+        const uint32_t offT = K.bloom_off, off5 = K.bloom_off + K.bloomT_bits / 8;
+        auto bit = [&] (uint32_t h, uint32_t scale, uint32_t off) -> uint32_t {
+          const uint32_t w = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (off + mul_hi_u24 (h, scale) * 4u);
+          return w >> (h & 31u);
         };
-        const uint32_t key5 = __umul24 (idx, K.W) + (pend_item[GRAM_DEPTH - 1].y >> 20);
-        const uint32_t t = bit (gram_bloom_slot (idx, K.bloomT_bits, 0)) & bit (gram_bloom_slot (idx, K.bloomT_bits, 1));
-        const uint32_t f = bit (K.bloomT_bits + gram_bloom_slot (key5, K.bloom5_bits, 0)) &
-                           bit (K.bloomT_bits + gram_bloom_slot (key5, K.bloom5_bits, 1));
-        need = need && ((t | f) != 0);
+        const uint32_t c5 = pend_item[GRAM_DEPTH - 1].y >> 20;
+        const uint32_t h1 = __umul24 (idx, BLOOM_C1), h2 = __umul24 (idx, BLOOM_C2);
+        const uint32_t t = bit (h1, scaleT, offT) & bit (h2, scaleT, offT);
+        const uint32_t f = bit (mad_u24 (c5, BLOOM_D1, h1), scale5, off5) & bit (mad_u24 (c5, BLOOM_D2, h2), scale5, off5);
+        need = need && (((t | f) & 1u) != 0);
       }
       /* (a lane that needs nothing asks for nothing: a gather costs by the line) */
       const uint32_t word = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
