@@ -181,33 +181,36 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     counted = (uint32_t)r;
     DIAG (d_walk += __builtin_readcyclecounter () - d_c0; d_calls++; d_items += n_items;)
   };
-  /* second sieve on the oldest pending batch: terminal, or the 5th symbol is an edge of the
-   * depth-4 state; then the pipeline moves up */
-  auto consume_oldest = [&] () {
+  /* Second sieve on the oldest pending batch, in three parts so that a pipeline step can put the
+   * LDS round trips of the NEW batch (its items, then its filter bits) behind them: a keyword of
+   * 4 symbols ends here; the 5th symbol is an edge of the depth-4 state; the pipeline moves up. */
+  auto consume_terminal = [&] () {
     if (pend_n[0]) {
-      const uint32_t c4 = pend_item[0].y >> 20;
-      bool valid = lane < pend_n[0];
       if (WIDE) {
         /* the slot that came back is the first of the probe sequence: a hit, an empty slot (the
          * Bloom bit was a false positive), or somebody else's window -- then probe on (rare) */
         uint2 e = make_uint2 (pend_rx[0], pend_ry[0]);
         uint32_t slot = (pend_item[0].y * WIDE_H2) >> (32 - K.wtab_log2);
-        while (valid && (e.y & ST_STATE) != 0 && e.x != pend_item[0].y) {
+        while (lane < pend_n[0] && (e.y & ST_STATE) != 0 && e.x != pend_item[0].y) {
           slot = (slot + 1) & ((1u << K.wtab_log2) - 1);
           e = K.wtab[slot];
         }
-        valid = valid && (e.y & ST_STATE) != 0;
         /* same shape as the exact table's record: terminal bit 31, "goes on" as bit 0 of the mask */
-        pend_rx[0] = (e.y & WT_TERM) | ((e.y & WT_KIDS) ? 1u : 0u);
+        pend_rx[0] = (e.y & ST_STATE) != 0 ? (e.y & WT_TERM) | ((e.y & WT_KIDS) ? 1u : 0u) : 0u;
         pend_ry[0] = e.y & ST_STATE;
       }
       /* a keyword of length 4 ends here: reported at once, its record needs nothing but the
        * state id (the trie records of the 508,339 states are 16 MB of HBM: not worth a visit) */
-      const bool term = valid && (pend_rx[0] >> 31) && pend_item[0].x + 3 >= E.emit_from;
+      const bool term = lane < pend_n[0] && (pend_rx[0] >> 31) && pend_item[0].x + 3 >= E.emit_from;
       emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, (pend_ry[0] - K.d4_begin) | HIT_LEN4, lane, hits, counted);
       if (!COUNT_ONLY)
         counted = uniform ((uint32_t)counted);
-      const bool pass = valid && ((pend_rx[0] >> (WIDE ? 0u : c4)) & 1u);
+    }
+  };
+  auto consume_pass = [&] () {
+    if (pend_n[0]) {
+      const uint32_t c4 = pend_item[0].y >> 20;
+      const bool pass = lane < pend_n[0] && ((pend_rx[0] >> (WIDE ? 0u : c4)) & 1u);
       const uint64_t m = __ballot (pass);
       if (m) {
         if (pass)
@@ -217,6 +220,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           walk_batch (WAVE);
       }
     }
+  };
+  auto pipeline_shift = [&] () {
     pend_item[0] = pend_item[1];
     pend_rx[0] = pend_rx[1];
     pend_ry[0] = pend_ry[1];
@@ -224,12 +229,10 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     pend_item[1] = pend_item[2];
     pend_n[1] = pend_n[2];
     pend_n[2] = 0;
-    if (WIDE)
-    {
+    if (WIDE) {
       pend_rx[1] = pend_rx[2];
       pend_ry[1] = pend_ry[2];
-    }
-    else {
+    } else {
       /* the batch that has just left the newest slot: its prefix counts are here, now the entries
        * (issued after the copies above, straight into the slot they will be read from) */
       asm volatile ("" : "+v"(pend_rx[0]), "+v"(pend_ry[0]), "+v"(pend_item[0].x), "+v"(pend_item[0].y),
@@ -243,36 +246,46 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       pend_ry[1] = K.d4_begin + rank;
     }
   };
-  /* takes the newest n items of the first queue and sends for their records (the last pipeline
-   * slot is free: consume_oldest ran just before) */
-  auto issue_batch = [&] (uint32_t n_items) {
+  auto consume_oldest = [&] () {
+    consume_terminal ();
+    consume_pass ();
+    pipeline_shift ();
+  };
+  /* One pipeline step: the oldest batch is consumed, the newest n items of the first queue take
+   * the slot that frees up and send for their records.  Narrow alphabets: the new batch's two LDS
+   * round trips (items; then the words of the two Bloom filters and of the 4-gram bits) are put
+   * behind the two halves of the consumption -- four waves per SIMD do not hide them. */
+  auto batch_step = [&] (uint32_t n_items) {
     qn1 -= n_items;
-    pend_item[GRAM_DEPTH - 1] = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
-    if (WIDE)
-    {
-      const uint2 e = K.wtab[(pend_item[GRAM_DEPTH - 1].y * WIDE_H2) >> (32 - K.wtab_log2)];
+    const uint2 it = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
+    if constexpr (WIDE) {
+      consume_oldest ();
+      pend_item[GRAM_DEPTH - 1] = it;
+      const uint2 e = K.wtab[(it.y * WIDE_H2) >> (32 - K.wtab_log2)];
       pend_rx[GRAM_DEPTH - 1] = e.x;
       pend_ry[GRAM_DEPTH - 1] = e.y;
-    }
-    else {
-      const uint32_t idx = pend_item[GRAM_DEPTH - 1].y & 0xFFFFFu;
-      bool need = lane < n_items;
-      if (K.bloom5_bits) {
-        /* (word scale and byte offset of the two filters: wave-uniform, in SGPRs) */
-        const uint32_t scaleT = (K.bloomT_bits / 32) << 8, scale5 = (K.bloom5_bits / 32) << 8;
-        const uint32_t offT = K.bloom_off, off5 = K.bloom_off + K.bloomT_bits / 8;
-        auto bit = [&] (uint32_t h, uint32_t scale, uint32_t off) -> uint32_t {
-          const uint32_t w = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (off + mul_hi_u24 (h, scale) * 4u);
-          return w >> (h & 31u);
-        };
-        const uint32_t c5 = pend_item[GRAM_DEPTH - 1].y >> 20;
-        const uint32_t h1 = __umul24 (idx, BLOOM_C1), h2 = __umul24 (idx, BLOOM_C2);
-        const uint32_t t = bit (h1, scaleT, offT) & bit (h2, scaleT, offT);
-        const uint32_t f = bit (mad_u24 (c5, BLOOM_D1, h1), scale5, off5) & bit (mad_u24 (c5, BLOOM_D2, h2), scale5, off5);
-        need = need && (((t | f) & 1u) != 0);
-      }
+    } else {
+      consume_terminal ();
+      const uint32_t idx = it.y & 0xFFFFFu, c5 = it.y >> 20;
+      /* the words of the two filters (word scale and byte offset: wave-uniform, in SGPRs; without
+       * filters scale 0 reads some word and the answer is ignored -- no branch here: a value
+       * loaded under one must be looked at before its block ends) and of the 4-gram bits */
+      const uint32_t scaleT = (K.bloomT_bits / 32) << 8, scale5 = (K.bloom5_bits / 32) << 8;
+      const uint32_t offT = K.bloom_off, off5 = K.bloom_off + K.bloomT_bits / 8;
+      auto lds_word = [&] (uint32_t byte_off) -> uint32_t {
+        return *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (byte_off);
+      };
+      const uint32_t h1 = __umul24 (idx, BLOOM_C1), h2 = __umul24 (idx, BLOOM_C2);
+      const uint32_t h3 = mad_u24 (c5, BLOOM_D1, h1), h4 = mad_u24 (c5, BLOOM_D2, h2);
+      const uint32_t w1 = lds_word (offT + mul_hi_u24 (h1, scaleT) * 4u), w2 = lds_word (offT + mul_hi_u24 (h2, scaleT) * 4u);
+      const uint32_t w3 = lds_word (off5 + mul_hi_u24 (h3, scale5) * 4u), w4 = lds_word (off5 + mul_hi_u24 (h4, scale5) * 4u);
+      const uint32_t word = lds_word ((idx >> 5) * 4u);
+      consume_pass ();
+      pipeline_shift ();
+      pend_item[GRAM_DEPTH - 1] = it;
+      const uint32_t tf = ((w1 >> (h1 & 31u)) & (w2 >> (h2 & 31u))) | ((w3 >> (h3 & 31u)) & (w4 >> (h4 & 31u))) | (K.bloom5_bits ? 0u : 1u);
       /* (a lane that needs nothing asks for nothing: a gather costs by the line) */
-      const uint32_t word = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
+      const bool need = lane < n_items && (tf & 1u) != 0;
       uint32_t pre = 0;
       if (need)
         pre = K.g4prefix[idx >> 5];
@@ -346,10 +359,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
             if (push)
               q1[qn1 + rank_below (m)] = make_uint2 (p, win[j]);
             qn1 = uniform (qn1 + (uint32_t)__popcll (m));
-            if (qn1 >= WAVE) {
-              consume_oldest ();
-              issue_batch (WAVE);
-            }
+            if (__builtin_expect (qn1 >= WAVE, 0))
+              batch_step (WAVE);
           }
         }
         if (SHORTS) {
@@ -446,10 +457,9 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           if (push)
             q1[qn1 + rank_below (m)] = make_uint2 (pos0 + 8 * h + j, lshl_or (c[8 * h + j + 4], 20u, ix[j]));
           qn1 = uniform (qn1 + (uint32_t)__popcll (m));
-          if (qn1 >= WAVE) {
+          if (__builtin_expect (qn1 >= WAVE, 0)) {
             DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)
-            consume_oldest ();
-            issue_batch (WAVE);
+            batch_step (WAVE);
             DIAG (d_cons += __builtin_readcyclecounter () - d_c1; d_b1++;)
           }
         }
@@ -473,10 +483,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       c3 = n3;
     }
   }
-  if (qn1) {
-    consume_oldest ();
-    issue_batch (qn1);
-  }
+  if (qn1)
+    batch_step (qn1);
 #pragma unroll
   for (int d = 0; d < GRAM_DEPTH; d++)
     consume_oldest ();
