@@ -11,10 +11,11 @@
  *      keyword starts with it".  Every position is tested with one ds_read_b32 on a rolling
  *      4-gram index (config 3: 19.6% pass);
  *   2. the survivors are queued per wave as (position, 4-gram index, class of the 5th symbol)
- *      and checked 64 at a time against an 8-byte record per 4-gram: {terminal bit | 26-bit mask
- *      of the depth-4 state's children, its state id}; three batches are in flight behind the
- *      scan (config 3: 3.2% of the positions pass -- all real: a keyword of length 4 ends there,
- *      reported on the spot, or a 5-symbol prefix of a keyword does);
+ *      and leave the queue 64 at a time: two Bloom filters in LDS say which of them can have
+ *      anything to report (GramK::bloom5_bits), those get the depth-4 state's {terminal bit | mask
+ *      of its children} by rank (GramK::g4prefix) in two pipelined gathers; two batches are in
+ *      flight behind the scan (config 3: 3.2% of the positions pass -- all real: a keyword of
+ *      length 4 ends there, reported on the spot, or a 5-symbol prefix of a keyword does);
  *   3. the latter (0.75%) go to walk_starts (shared with the start-parallel kernel) at the
  *      depth-4 state; the trie records below depth 4 are laid out depth-first.
  * Keywords of 1-3 symbols (template SHORTS, only if the dictionary has any): a nibble per 3-gram
@@ -26,7 +27,7 @@
  * Text is read as in the start-parallel kernel (1 KiB groups, 16 bytes per lane, four groups in
  * flight). */
 struct GramK {
-  const uint2 *g4rec;     /* [W^4] {children mask | terminal << 31, state id of the depth-4 node (0: none)} */
+  const uint2 *g4rec;     /* [W^4] {children mask | terminal << 31, state id of the depth-4 node (0: none)} (sieve kernel only) */
   const uint32_t *g4bits; /* [g4words] one bit per 4-gram, staged in LDS */
   const uint4 *srec;      /* trie records of the states of depth >= 4, depth-first order (see StartsK::remap) */
   const uint2 *sedge;

@@ -897,6 +897,16 @@ def _random_case(rng, kind):
         kws = [rng.integers(97, 97 + span, size=rng.integers(4, 13)).astype(np.uint8) for _ in range(int(rng.integers(11000, 14000)))]
         text = rng.integers(96, 97 + span + 1, size=int(rng.integers(50000, 400000))).astype(np.uint8)
         return kws, text, 1, ({"ACM_GPU_GRAM": "0"} if kind == "sticky" else {})
+    if kind == "gram30":            # the widest alphabet the exact 4-gram index takes (28-30 classes), Bloom filters on
+        lo = int(rng.integers(0, 200)); span = int(rng.integers(27, 30))
+        kws = [rng.integers(lo, lo + span, size=rng.integers(4, 10)).astype(np.uint8) for _ in range(int(rng.integers(11000, 13000)))]
+        text = rng.integers(max(lo - 1, 0), lo + span + 1, size=int(rng.integers(50000, 300000))).astype(np.uint8)
+        for _ in range(3000):       # keyword heads of 4 to 6 symbols: the filters and the rank tables see hits and near misses
+            w = kws[int(rng.integers(0, len(kws)))]
+            k = min(w.size, 4 + int(rng.integers(0, 3)))
+            at = int(rng.integers(0, text.size - 12))
+            text[at:at + k] = w[:k]
+        return kws, text, 1, {}
     if kind == "gramsmall":         # the 4-gram kernel forced onto small dictionaries (few 4-grams set, lmax down to 4)
         lo = int(rng.integers(0, 220)); span = int(rng.integers(1, 29))
         top = int(rng.integers(5, 12))
@@ -942,7 +952,7 @@ def _random_case(rng, kind):
     return kws, text, sym, ({"ACM_GPU_SPARSE": "walk"} if kind.startswith("walk") else {})
 
 
-@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "sieve", "gram", "gramsmall", "wide", "wideshort", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
+@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "sieve", "gram", "gram30", "gramsmall", "wide", "wideshort", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
                                        for s in range(int(os.environ.get("ACM_SOAK_SEEDS", "3")))])   # ACM_SOAK_SEEDS=14: a soak run
 def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed):
     """Random dictionaries and texts through every kernel family; whole scans, count-only scans and
@@ -961,8 +971,8 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
             text[at:at + w.size] = w
     m, o = build_pair(kws, sym)
     plan = m.plan(0)
-    expect = {"dense": 1, "sieve": 6, "gram": 5, "gramsmall": 5, "wide": 5, "wideshort": 5, "sticky": 1, "short": 5, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
-    if kind in ("gram", "wide", "wideshort", "sticky", "short"):
+    expect = {"dense": 1, "sieve": 6, "gram": 5, "gram30": 5, "gramsmall": 5, "wide": 5, "wideshort": 5, "sticky": 1, "short": 5, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
+    if kind in ("gram", "gram30", "wide", "wideshort", "sticky", "short"):
         assert plan.info.dense_rows > 32768, "the generator is meant to give more states than the LDS scheme takes"
     if kind == "dense":     # small dictionaries whose hot rows outgrow LDS go to the 4-gram kernel by themselves
         assert plan.info.kernel in (1, 5, 6), plan.info.kernel
