@@ -67,6 +67,7 @@ namespace {
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
 constexpr int QCAP = 128;           /* per-wave queue of (position, state) items, 8 B each */
+constexpr uint32_t GRAM_NO_PEEK = 0xFFFFFFFFu; /* 4-gram kernel, GramK::g5peek: the state's record has to be looked at */
 constexpr int DENSE_THREADS = 1024; /* one workgroup per CU, 16 waves */
 /* dense kernel geometry: C = 64 bytes per lane-stream per tile, S = 2 streams per lane
  * (-DACM_DENSE_S=n builds another stream count for experiments: 3 and 4 spill and are 2x slower) */
@@ -478,7 +479,8 @@ struct GramImage {
   uint32_t *bits, *g4, *rec, *edge, *g4gid; /* first-stage bits, second-stage records, trie records (depth-first), their edges, depth-4 state -> record */
   unsigned char *nib;                      /* narrow alphabets: nibble per 3-gram */
   uint32_t *tri;                           /* trigram sieve kernel: [W * W] words, bit c2 of word c0 * W + c1 (NULL: not wanted) */
-  uint32_t *prefix, *entry;                /* narrow alphabets: set bits before each word of `bits`; children mask | terminal << 31 by rank */
+  uint32_t *prefix, *entry;                /* narrow alphabets: set bits before each word of `bits`; by rank {children mask | terminal << 31, first child's state id} */
+  uint32_t *peek;                          /* narrow alphabets: per depth-5 state {its record, the symbol of its only edge or GRAM_NO_PEEK} */
   uint32_t *bloom;                         /* narrow alphabets: Bloom bits, terminal 4-grams then 5-grams (GramK::bloom5_bits; NULL: none) */
   uint32_t bloomT_bits, bloom5_bits, lo;
   uint32_t *g3, *stab;                     /* short keywords: prefix states per 3-gram (narrow) / table of tagged windows (wide) */
@@ -523,6 +525,16 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
         slots++;
       }
     }
+    /* what a walk that starts at a depth-5 state asks first (GramK::g5peek): where its record is,
+     * and -- when the state is no keyword's end and has one way on -- the symbol that way takes,
+     * so that 25 of 26 candidates end on 8 bytes that stay in L2 instead of a 32-byte record
+     * from the 16 MB of them */
+    const uint32_t d5_end = fi.lmax >= 5 ? fv.depth_start[6 <= fi.lmax + 1 ? 6 : fi.lmax + 1] : fv.depth_start[5];
+    for (uint32_t st = fv.depth_start[5]; G.peek && fi.lmax >= 5 && st < d5_end; st++) {
+      const uint32_t b0 = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b0;
+      G.peek[2 * (size_t)(st - fv.depth_start[5])] = gid[st];
+      G.peek[2 * (size_t)(st - fv.depth_start[5]) + 1] = (ne == 1 && fv.term_kw[st] == NONE) ? fv.edge_sym[b0] : GRAM_NO_PEEK;
+    }
   }
   /* base-W number of the path of every state down to depth 4 (parents come first in
    * breadth-first order); the depth-4 states are the 4-grams some keyword starts with */
@@ -551,7 +563,8 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     bits[idx >> 5] |= 1u << (idx & 31);
     g4[2 * (size_t)idx] = mask;
     g4[2 * (size_t)idx + 1] = st;
-    G.entry[st - fv.depth_start[4]] = mask;
+    G.entry[2 * (size_t)(st - fv.depth_start[4])] = mask;
+    G.entry[2 * (size_t)(st - fv.depth_start[4]) + 1] = fv.row_ptr[st + 1] > fv.row_ptr[st] ? fv.edge_next[fv.row_ptr[st]] : 0u;
     if (G.bloom) {
       auto set = [&] (uint32_t slot) { G.bloom[slot >> 5] |= 1u << (slot & 31); };
       if (fv.term_kw[st] != NONE) {
@@ -842,7 +855,9 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const size_t o_g4gid = blob_reserve (cur, gram ? (size_t)(fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1] - fv.depth_start[4]) * 4 + 16 : 0);
   const size_t o_kw4 = blob_reserve (cur, gram ? (size_t)n_depth4 * 4 + 16 : 0);
   const size_t o_g4prefix = blob_reserve (cur, gram && !gram_wide ? (size_t)g4words * 4 + 16 : 0);
-  const size_t o_g4entry = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth4 * 4 + 16 : 0);
+  const size_t o_g4entry = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth4 * 8 + 16 : 0);
+  const uint32_t n_depth5 = gram && fi.lmax >= 5 ? fv.depth_start[6 <= fi.lmax + 1 ? 6 : fi.lmax + 1] - fv.depth_start[5] : 0;
+  const size_t o_g5peek = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth5 * 8 + 16 : 0);
   const bool sieve = gram && sieve_want;
   const size_t o_tri = blob_reserve (cur, sieve ? (size_t)gW * gW * 4 + 16 : 0);
   p->blob_bytes = cur;
@@ -892,6 +907,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     G.tri = sieve ? reinterpret_cast<uint32_t *> (&host[o_tri]) : nullptr;
     G.prefix = reinterpret_cast<uint32_t *> (&host[o_g4prefix]);
     G.entry = reinterpret_cast<uint32_t *> (&host[o_g4entry]);
+    G.peek = gram_wide ? nullptr : reinterpret_cast<uint32_t *> (&host[o_g5peek]);
     G.bloom = bloom5_bits ? reinterpret_cast<uint32_t *> (&host[o_g4bits + bloom_off]) : nullptr;
     G.bloomT_bits = bloomT_bits;
     G.bloom5_bits = bloom5_bits;
@@ -1003,7 +1019,9 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     if ((uint64_t)bits_bytes + gq + WALK_CTX_BYTES <= lds_total) {
       p->d_kw4 = u32p (o_kw4);
       p->GK.g4prefix = u32p (o_g4prefix);
-      p->GK.g4entry = u32p (o_g4entry);
+      p->GK.g4entry = reinterpret_cast<const uint2 *> (b + o_g4entry);
+      p->GK.g5peek = reinterpret_cast<const uint2 *> (b + o_g5peek);
+      p->GK.d5_begin = fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1];
       p->GK.bloom_off = bloom_off;
       p->GK.bloomT_bits = bloomT_bits;
       p->GK.bloom5_bits = bloom5_bits;

@@ -64,7 +64,14 @@ struct GramK {
    * bytes per existing 4-gram (config 3: 360 KB) that stay in L2, where the 8-byte records by
    * index (W^4 of them, 4.25 MB for a-z) did not fit beside the text streaming through: two of
    * three record gathers went to memory for a 128-byte line each, 5.5 x the algorithmic bytes. */
-  const uint32_t *g4prefix, *g4entry;
+  const uint32_t *g4prefix;
+  const uint2 *g4entry;   /* by rank: {children mask | terminal << 31, state id of the first child} */
+  /* the walks start one level down, at the depth-5 state the 5th symbol leads to (children are
+   * numbered consecutively in symbol order: first child + set mask bits below the class), and ask
+   * g5peek[that state - d5_begin] = {its record, the symbol of its only edge | GRAM_NO_PEEK}
+   * before any record: 708 KB that stay in L2 */
+  const uint2 *g5peek;
+  uint32_t d5_begin;
   uint32_t R;             /* groups per tile */
   uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
 };
@@ -128,7 +135,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     Kc.srec = K.srec;
     Kc.sedge = K.sedge;
     Kc.remap = K.g4gid;
-    Kc.remap_base = K.d4_begin;
+    Kc.remap_base = WIDE ? K.d4_begin : K.d5_begin;
+    Kc.peek = K.g5peek;
     *Ks = Kc;
     *Es = E;
   }
@@ -161,7 +169,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   constexpr int GRAM_DEPTH = 3;
   DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_items = 0, d_b1 = 0, d_cons = 0, d_tiles = 0;)
   uint2 pend_item[GRAM_DEPTH];
-  uint32_t pend_rx[GRAM_DEPTH], pend_ry[GRAM_DEPTH]; /* the record's two words, apart: a 64-bit register pair half in flight pins both */
+  uint32_t pend_rx[GRAM_DEPTH], pend_ry[GRAM_DEPTH], pend_rz[2] = { 0, 0 }; /* the record's words, apart: a 64-bit register pair half in flight pins both (rz: narrow alphabets, the first child) */
   uint32_t pend_n[GRAM_DEPTH]; /* wave-uniform: items in each pending batch, [0] the oldest */
   constexpr uint32_t PEND_NEED = 0x80000000u;
 #pragma unroll
@@ -177,7 +185,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   };
   auto walk_batch = [&] (uint32_t n_items) {
     DIAG (const unsigned long long d_c0 = __builtin_readcyclecounter ();)
-    const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, true> (Ks, Es, text, q2, qn2, n_items, hits, counted);
+    const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, WIDE ? 1 : 2> (Ks, Es, text, q2, qn2, n_items, hits, counted);
     qn2 = uniform ((uint32_t)(r >> 32));
     counted = (uint32_t)r;
     DIAG (d_walk += __builtin_readcyclecounter () - d_c0; d_calls++; d_items += n_items;)
@@ -214,8 +222,12 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       const bool pass = lane < pend_n[0] && ((pend_rx[0] >> (WIDE ? 0u : c4)) & 1u);
       const uint64_t m = __ballot (pass);
       if (m) {
-        if (pass)
-          q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 3, pend_ry[0] | WI_REPORTED);
+        if (pass) {
+          if (WIDE)
+            q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 3, pend_ry[0] | WI_REPORTED);
+          else /* the depth-5 state, at the 5th symbol */
+            q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 4, pend_rz[0] + __popc (pend_rx[0] & ((1u << c4) - 1u)));
+        }
         qn2 = uniform (qn2 + (uint32_t)__popcll (m));
         while (qn2 >= WAVE)
           walk_batch (WAVE);
@@ -226,6 +238,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     pend_item[0] = pend_item[1];
     pend_rx[0] = pend_rx[1];
     pend_ry[0] = pend_ry[1];
+    pend_rz[0] = pend_rz[1];
     pend_n[0] = pend_n[1];
     pend_item[1] = pend_item[2];
     pend_n[1] = pend_n[2];
@@ -236,14 +249,15 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     } else {
       /* the batch that has just left the newest slot: its prefix counts are here, now the entries
        * (issued after the copies above, straight into the slot they will be read from) */
-      asm volatile ("" : "+v"(pend_rx[0]), "+v"(pend_ry[0]), "+v"(pend_item[0].x), "+v"(pend_item[0].y),
+      asm volatile ("" : "+v"(pend_rx[0]), "+v"(pend_ry[0]), "+v"(pend_rz[0]), "+v"(pend_item[0].x), "+v"(pend_item[0].y),
                     "+v"(pend_item[1].x), "+v"(pend_item[1].y));
       __builtin_amdgcn_sched_barrier (0);
       const uint32_t rank = pend_rx[2] + (pend_ry[2] & ~PEND_NEED);
-      uint32_t ent = 0;
+      uint2 ent = make_uint2 (0, 0);
       if (pend_n[1] && (pend_ry[2] & PEND_NEED))
         ent = K.g4entry[rank];
-      pend_rx[1] = ent;
+      pend_rx[1] = ent.x;
+      pend_rz[1] = ent.y;
       pend_ry[1] = K.d4_begin + rank;
     }
   };

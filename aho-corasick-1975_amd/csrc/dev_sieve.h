@@ -95,7 +95,7 @@ scan_sieve_kernel (SieveK S, EmitCtx E, Launch A, const unsigned char *__restric
   };
   auto cls = [&] (uint32_t byte) -> uint32_t { return min (byte - K.lo, K.span); };
   auto walk_batch = [&] (uint32_t n_items) {
-    const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, true> (Ks, Es, text, q2, qn2, n_items, hits, counted);
+    const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, 1> (Ks, Es, text, q2, qn2, n_items, hits, counted);
     qn2 = uniform ((uint32_t)(r >> 32));
     counted = (uint32_t)r;
   };

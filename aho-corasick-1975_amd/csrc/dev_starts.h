@@ -36,6 +36,10 @@ struct StartsK {
    * remap_base] is its record, and word 0 of a record is the state's breadth-first id */
   const uint32_t *remap;
   uint32_t remap_base;
+  /* 4-gram kernel, narrow alphabets (walk_starts<.., 2>): an item without WI_RECORD names a
+   * depth-5 state; peek[id - remap_base] = {its record, the symbol of its only edge or
+   * GRAM_NO_PEEK} */
+  const uint2 *peek;
 };
 constexpr uint32_t ST_ALWAYS = 0x80000000u, ST_SECOND = 0x40000000u, ST_STATE = 0x3FFFFFFFu;
 
@@ -205,7 +209,7 @@ constexpr uint32_t WALK_CTX_K = 128, WALK_CTX_BYTES = 16 + 128 + 256; /* LDS aft
 static_assert (sizeof (StartsK) <= WALK_CTX_K && sizeof (EmitCtx) <= 256, "walk context does not fit its LDS slot");
 constexpr uint32_t WI_REPORTED = 0x80000000u; /* what ends in this state has been reported by the caller */
 constexpr uint32_t WI_RECORD = 0x40000000u;   /* 4-gram kernel: the index is a record index already (StartsK::remap) */
-template <typename SYM, bool COUNT_ONLY, bool GRAM = false>
+template <typename SYM, bool COUNT_ONLY, int GRAM = 0>
 __device__ __noinline__ unsigned long long
 walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue, uint32_t qn, uint32_t n_items, uint2 *hits,
              unsigned long long counted) {
@@ -217,15 +221,27 @@ walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue
   const uint2 it = alive ? queue[base + lane] : make_uint2 (0, 0);
   const uint32_t p = it.x;
   uint32_t st = it.y & ST_STATE;
-  if (GRAM && !(it.y & WI_RECORD))
+  /* GRAM == 2: a fresh item (a depth-5 state by its id) asks the peek table first and comes back
+   * as a record item at the same position if the next symbol can go on (or the state's record has
+   * to be seen anyway); only record items touch the records */
+  const bool fresh = GRAM == 2 && alive && !(it.y & WI_RECORD);
+  uint2 pk = make_uint2 (0, 0);
+  if (fresh)
+    pk = K.peek[st - K.remap_base];
+  if (GRAM == 1 && !(it.y & WI_RECORD))
     st = alive ? K.remap[st - K.remap_base] : 0u;
-  const uint4 ra = K.srec[2 * st], rb = K.srec[2 * st + 1];
+  const bool regular = alive && !fresh;
+  uint4 ra = make_uint4 (0, 0, 0, 0), rb = make_uint4 (0, 0, 0, 0);
+  if (GRAM != 2 || regular) {
+    ra = K.srec[2 * st];
+    rb = K.srec[2 * st + 1];
+  }
   const bool more = alive && p + 1 < E.n;
   const uint32_t c1 = more ? (uint32_t)text[p + 1] : 0u;
-  emit_terminals<COUNT_ONLY> (E, alive && !(it.y & WI_REPORTED) && ra.w != 0 && p >= E.emit_from, p, GRAM ? ra.x : st, lane, hits,
+  emit_terminals<COUNT_ONLY> (E, regular && !(it.y & WI_REPORTED) && ra.w != 0 && p >= E.emit_from, p, GRAM ? ra.x : st, lane, hits,
                               counted);
   uint32_t nx = NONE;
-  if (more) {
+  if (more && regular) {
     const uint32_t ne = ra.y;
     if (ne >= 1 && rb.x == c1)
       nx = rb.y;
@@ -247,10 +263,11 @@ walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue
       }
     }
   }
-  const bool go = nx != NONE;
+  const bool on = fresh && (pk.y == GRAM_NO_PEEK || (more && pk.y == c1));
+  const bool go = nx != NONE || on;
   const uint64_t m = __ballot (go);
   if (go)
-    queue[base + rank_below (m)] = make_uint2 (p + 1, nx | (GRAM ? WI_RECORD : 0u));
+    queue[base + rank_below (m)] = on ? make_uint2 (p, pk.x | WI_RECORD) : make_uint2 (p + 1, nx | (GRAM ? WI_RECORD : 0u));
   const uint32_t fill = base + (uint32_t)__popcll (m);
   if (COUNT_ONLY)
     return ((unsigned long long)fill << 32) | (uint32_t)counted;
