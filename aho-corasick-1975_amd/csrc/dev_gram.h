@@ -344,11 +344,18 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   };
 
   /* one group: cur = this lane's 16 bytes, next_x = the first 4 bytes of every lane of the next group */
-  auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t g) {
+  auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t g, uint4 &prefetched) {
     uint32_t after = __shfl_down (cur.x, 1, WAVE);
     const uint32_t after_group = uniform (next_x);
     if (lane == WAVE - 1)
       after = after_group;
+    /* the group four ahead is asked for HERE, after the first look at this one: the compiler
+     * cannot count the loads in flight across the pipeline steps' gathers and waits for all of
+     * them (vmcnt(0)) wherever it waits -- asked for before that first look, the prefetch was
+     * waited for on the spot, one HBM latency per group and wave */
+    asm volatile ("" : "+v"(after));
+    __builtin_amdgcn_sched_barrier (0);
+    prefetched = load_group (g + 4);
     const uint32_t pos0 = g * GROUP + lane * 16;
     const uint32_t w[5] = { cur.x, cur.y, cur.z, cur.w, after };
     if constexpr (WIDE) {
@@ -490,8 +497,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     const uint32_t g0 = tile * K.R;
     uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
     for (uint32_t k = 0; k < K.R; k++) {
-      const uint4 n3 = load_group (g0 + k + 4);
-      walk_group (c0, c1.x, g0 + k);
+      uint4 n3;
+      walk_group (c0, c1.x, g0 + k, n3);
       c0 = c1;
       c1 = c2;
       c2 = c3;
