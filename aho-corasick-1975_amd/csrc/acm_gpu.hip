@@ -115,6 +115,7 @@ struct EmitCtx {
   uint32_t chain_base;
 };
 constexpr uint32_t HIT_LEN4 = 0x80000000u;
+constexpr uint32_t HIT_KW4 = 0x40000000u; /* the hit's word is the keyword id itself (a keyword of 4 symbols, id below 2^30) */
 
 /* one launch: a segment of the buffer, positions relative to its first symbol */
 struct Launch {
@@ -479,10 +480,10 @@ struct GramImage {
   uint32_t *bits, *g4, *rec, *edge, *g4gid; /* first-stage bits, second-stage records, trie records (depth-first), their edges, depth-4 state -> record */
   unsigned char *nib;                      /* narrow alphabets: nibble per 3-gram */
   uint32_t *tri;                           /* trigram sieve kernel: [W * W] words, bit c2 of word c0 * W + c1 (NULL: not wanted) */
-  uint32_t *prefix, *entry;                /* narrow alphabets: set bits before each word of `bits`; by rank {children mask | terminal << 31, first child's state id} */
+  uint32_t *prefix, *entry;                /* narrow alphabets: set bits before each word of `bits`; by rank {children mask | terminal << 31, first child's state id, keyword id, -} */
   uint32_t *peek;                          /* narrow alphabets: per depth-5 state {its record, the symbol of its only edge or GRAM_NO_PEEK} */
   uint32_t *bloom;                         /* narrow alphabets: Bloom bits, terminal 4-grams then 5-grams (GramK::bloom5_bits; NULL: none) */
-  uint32_t bloomT_bits, bloom5_bits, lo;
+  uint32_t bloomT_bits, bloom5_bits, lo, kw_base;
   uint32_t *g3, *stab;                     /* short keywords: prefix states per 3-gram (narrow) / table of tagged windows (wide) */
 };
 
@@ -563,8 +564,9 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     bits[idx >> 5] |= 1u << (idx & 31);
     g4[2 * (size_t)idx] = mask;
     g4[2 * (size_t)idx + 1] = st;
-    G.entry[2 * (size_t)(st - fv.depth_start[4])] = mask;
-    G.entry[2 * (size_t)(st - fv.depth_start[4]) + 1] = fv.row_ptr[st + 1] > fv.row_ptr[st] ? fv.edge_next[fv.row_ptr[st]] : 0u;
+    G.entry[4 * (size_t)(st - fv.depth_start[4])] = mask;
+    G.entry[4 * (size_t)(st - fv.depth_start[4]) + 1] = fv.row_ptr[st + 1] > fv.row_ptr[st] ? fv.edge_next[fv.row_ptr[st]] : 0u;
+    G.entry[4 * (size_t)(st - fv.depth_start[4]) + 2] = fv.term_kw[st] == NONE ? NONE : fv.term_kw[st] + G.kw_base;
     if (G.bloom) {
       auto set = [&] (uint32_t slot) { G.bloom[slot >> 5] |= 1u << (slot & 31); };
       if (fv.term_kw[st] != NONE) {
@@ -855,7 +857,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const size_t o_g4gid = blob_reserve (cur, gram ? (size_t)(fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1] - fv.depth_start[4]) * 4 + 16 : 0);
   const size_t o_kw4 = blob_reserve (cur, gram ? (size_t)n_depth4 * 4 + 16 : 0);
   const size_t o_g4prefix = blob_reserve (cur, gram && !gram_wide ? (size_t)g4words * 4 + 16 : 0);
-  const size_t o_g4entry = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth4 * 8 + 16 : 0);
+  const size_t o_g4entry = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth4 * 16 + 16 : 0);
   const uint32_t n_depth5 = gram && fi.lmax >= 5 ? fv.depth_start[6 <= fi.lmax + 1 ? 6 : fi.lmax + 1] - fv.depth_start[5] : 0;
   const size_t o_g5peek = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth5 * 8 + 16 : 0);
   const bool sieve = gram && sieve_want;
@@ -912,6 +914,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     G.bloomT_bits = bloomT_bits;
     G.bloom5_bits = bloom5_bits;
     G.lo = fi.alpha_lo;
+    G.kw_base = kw_base;
     fill_gram_tables (fv, fi, G);
   }
   if (dense) {
@@ -1019,7 +1022,8 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     if ((uint64_t)bits_bytes + gq + WALK_CTX_BYTES <= lds_total) {
       p->d_kw4 = u32p (o_kw4);
       p->GK.g4prefix = u32p (o_g4prefix);
-      p->GK.g4entry = reinterpret_cast<const uint2 *> (b + o_g4entry);
+      p->GK.g4entry = reinterpret_cast<const uint4 *> (b + o_g4entry);
+      p->GK.kw_inline = (uint64_t)fi.n_keywords + kw_base < HIT_KW4 ? 1u : 0u;
       p->GK.g5peek = reinterpret_cast<const uint2 *> (b + o_g5peek);
       p->GK.d5_begin = fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1];
       p->GK.bloom_off = bloom_off;

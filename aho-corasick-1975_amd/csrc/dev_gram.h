@@ -65,7 +65,8 @@ struct GramK {
    * index (W^4 of them, 4.25 MB for a-z) did not fit beside the text streaming through: two of
    * three record gathers went to memory for a 128-byte line each, 5.5 x the algorithmic bytes. */
   const uint32_t *g4prefix;
-  const uint2 *g4entry;   /* by rank: {children mask | terminal << 31, state id of the first child} */
+  const uint4 *g4entry;   /* by rank: {children mask | terminal << 31, state id of the first child, keyword id, -} */
+  uint32_t kw_inline;     /* keyword ids fit a hit's word beside HIT_KW4 (always, short of 2^30 keywords) */
   /* the walks start one level down, at the depth-5 state the 5th symbol leads to (children are
    * numbered consecutively in symbol order: first child + set mask bits below the class), and ask
    * g5peek[that state - d5_begin] = {its record, the symbol of its only edge | GRAM_NO_PEEK}
@@ -169,7 +170,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   constexpr int GRAM_DEPTH = 3;
   DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_items = 0, d_b1 = 0, d_cons = 0, d_tiles = 0;)
   uint2 pend_item[GRAM_DEPTH];
-  uint32_t pend_rx[GRAM_DEPTH], pend_ry[GRAM_DEPTH], pend_rz[2] = { 0, 0 }; /* the record's words, apart: a 64-bit register pair half in flight pins both (rz: narrow alphabets, the first child) */
+  uint32_t pend_rx[GRAM_DEPTH], pend_ry[GRAM_DEPTH], pend_rz[1] = { 0 }, pend_rw[1] = { 0 };
+  uint4 pend_e1 = make_uint4 (0, 0, 0, 0); /* the record's words, apart: a 64-bit register pair half in flight pins both (rz: narrow alphabets, the first child) */
   uint32_t pend_n[GRAM_DEPTH]; /* wave-uniform: items in each pending batch, [0] the oldest */
   constexpr uint32_t PEND_NEED = 0x80000000u;
 #pragma unroll
@@ -211,7 +213,10 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       /* a keyword of length 4 ends here: reported at once, its record needs nothing but the
        * state id (the trie records of the 508,339 states are 16 MB of HBM: not worth a visit) */
       const bool term = lane < pend_n[0] && (pend_rx[0] >> 31) && pend_item[0].x + 3 >= E.emit_from;
-      emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, (pend_ry[0] - K.d4_begin) | HIT_LEN4, lane, hits, counted);
+      /* (narrow alphabets: the entry brought the keyword's id along, and the hit carries it --
+       * expand_hits_kernel spent 0.2 of its 0.52 ms per 2 GiB of config 3 on the gather by rank) */
+      const uint32_t what = (!WIDE && K.kw_inline) ? pend_rw[0] | HIT_KW4 : (pend_ry[0] - K.d4_begin) | HIT_LEN4;
+      emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, what, lane, hits, counted);
       if (!COUNT_ONLY)
         counted = uniform ((uint32_t)counted);
     }
@@ -236,28 +241,31 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   };
   auto pipeline_shift = [&] () {
     pend_item[0] = pend_item[1];
-    pend_rx[0] = pend_rx[1];
     pend_ry[0] = pend_ry[1];
-    pend_rz[0] = pend_rz[1];
     pend_n[0] = pend_n[1];
     pend_item[1] = pend_item[2];
     pend_n[1] = pend_n[2];
     pend_n[2] = 0;
     if (WIDE) {
+      pend_rx[0] = pend_rx[1];
       pend_rx[1] = pend_rx[2];
       pend_ry[1] = pend_ry[2];
     } else {
+      /* the middle batch's entries came in one 16-byte gather (a register tuple: it stays where
+       * it landed until its words are copied out here, one step later) */
+      pend_rx[0] = pend_e1.x;
+      pend_rz[0] = pend_e1.y;
+      pend_rw[0] = pend_e1.z;
       /* the batch that has just left the newest slot: its prefix counts are here, now the entries
-       * (issued after the copies above, straight into the slot they will be read from) */
-      asm volatile ("" : "+v"(pend_rx[0]), "+v"(pend_ry[0]), "+v"(pend_rz[0]), "+v"(pend_item[0].x), "+v"(pend_item[0].y),
+       * (issued after the copies above, straight into the tuple they will be read from) */
+      asm volatile ("" : "+v"(pend_rx[0]), "+v"(pend_ry[0]), "+v"(pend_rz[0]), "+v"(pend_rw[0]), "+v"(pend_item[0].x), "+v"(pend_item[0].y),
                     "+v"(pend_item[1].x), "+v"(pend_item[1].y));
       __builtin_amdgcn_sched_barrier (0);
       const uint32_t rank = pend_rx[2] + (pend_ry[2] & ~PEND_NEED);
-      uint2 ent = make_uint2 (0, 0);
+      uint4 ent = make_uint4 (0, 0, 0, 0);
       if (pend_n[1] && (pend_ry[2] & PEND_NEED))
         ent = K.g4entry[rank];
-      pend_rx[1] = ent.x;
-      pend_rz[1] = ent.y;
+      pend_e1 = ent;
       pend_ry[1] = K.d4_begin + rank;
     }
   };
