@@ -480,10 +480,11 @@ struct GramImage {
   uint32_t *bits, *g4, *rec, *edge, *g4gid; /* first-stage bits, second-stage records, trie records (depth-first), their edges, depth-4 state -> record */
   unsigned char *nib;                      /* narrow alphabets: nibble per 3-gram */
   uint32_t *tri;                           /* trigram sieve kernel: [W * W] words, bit c2 of word c0 * W + c1 (NULL: not wanted) */
-  uint32_t *prefix, *entry;                /* narrow alphabets: set bits before each word of `bits`; by rank {children mask | terminal << 31, first child's state id, keyword id, -} */
+  uint32_t *prefix, *entry;                /* narrow alphabets: set bits before each word of `bits`; by rank {children mask | terminal << 31, first child's state id, keyword id} */
   uint32_t *peek;                          /* narrow alphabets: per depth-5 state {its record, the symbol of its only edge or GRAM_NO_PEEK} */
   uint32_t *bloom;                         /* narrow alphabets: Bloom bits, terminal 4-grams then 5-grams (GramK::bloom5_bits; NULL: none) */
   uint32_t bloomT_bits, bloom5_bits, lo, kw_base;
+  bool peek_packed;                        /* 4 bytes per depth-5 state (fewer than 2^23 records) instead of 8 */
   uint32_t *g3, *stab;                     /* short keywords: prefix states per 3-gram (narrow) / table of tagged windows (wide) */
 };
 
@@ -533,8 +534,13 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     const uint32_t d5_end = fi.lmax >= 5 ? fv.depth_start[6 <= fi.lmax + 1 ? 6 : fi.lmax + 1] : fv.depth_start[5];
     for (uint32_t st = fv.depth_start[5]; G.peek && fi.lmax >= 5 && st < d5_end; st++) {
       const uint32_t b0 = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b0;
-      G.peek[2 * (size_t)(st - fv.depth_start[5])] = gid[st];
-      G.peek[2 * (size_t)(st - fv.depth_start[5]) + 1] = (ne == 1 && fv.term_kw[st] == NONE) ? fv.edge_sym[b0] : GRAM_NO_PEEK;
+      const uint32_t sym = (ne == 1 && fv.term_kw[st] == NONE) ? fv.edge_sym[b0] : GRAM_NO_PEEK;
+      if (G.peek_packed) /* record | symbol << 23 | "look at the record" << 31 */
+        G.peek[st - fv.depth_start[5]] = gid[st] | (sym == GRAM_NO_PEEK ? 0x80000000u : sym << 23);
+      else {
+        G.peek[2 * (size_t)(st - fv.depth_start[5])] = gid[st];
+        G.peek[2 * (size_t)(st - fv.depth_start[5]) + 1] = sym;
+      }
     }
   }
   /* base-W number of the path of every state down to depth 4 (parents come first in
@@ -564,9 +570,9 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     bits[idx >> 5] |= 1u << (idx & 31);
     g4[2 * (size_t)idx] = mask;
     g4[2 * (size_t)idx + 1] = st;
-    G.entry[4 * (size_t)(st - fv.depth_start[4])] = mask;
-    G.entry[4 * (size_t)(st - fv.depth_start[4]) + 1] = fv.row_ptr[st + 1] > fv.row_ptr[st] ? fv.edge_next[fv.row_ptr[st]] : 0u;
-    G.entry[4 * (size_t)(st - fv.depth_start[4]) + 2] = fv.term_kw[st] == NONE ? NONE : fv.term_kw[st] + G.kw_base;
+    G.entry[3 * (size_t)(st - fv.depth_start[4])] = mask;
+    G.entry[3 * (size_t)(st - fv.depth_start[4]) + 1] = fv.row_ptr[st + 1] > fv.row_ptr[st] ? fv.edge_next[fv.row_ptr[st]] : 0u;
+    G.entry[3 * (size_t)(st - fv.depth_start[4]) + 2] = fv.term_kw[st] == NONE ? NONE : fv.term_kw[st] + G.kw_base;
     if (G.bloom) {
       auto set = [&] (uint32_t slot) { G.bloom[slot >> 5] |= 1u << (slot & 31); };
       if (fv.term_kw[st] != NONE) {
@@ -857,9 +863,9 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const size_t o_g4gid = blob_reserve (cur, gram ? (size_t)(fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1] - fv.depth_start[4]) * 4 + 16 : 0);
   const size_t o_kw4 = blob_reserve (cur, gram ? (size_t)n_depth4 * 4 + 16 : 0);
   const size_t o_g4prefix = blob_reserve (cur, gram && !gram_wide ? (size_t)g4words * 4 + 16 : 0);
-  const size_t o_g4entry = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth4 * 16 + 16 : 0);
+  const size_t o_g4entry = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth4 * 12 + 16 : 0);
   const uint32_t n_depth5 = gram && fi.lmax >= 5 ? fv.depth_start[6 <= fi.lmax + 1 ? 6 : fi.lmax + 1] - fv.depth_start[5] : 0;
-  const size_t o_g5peek = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth5 * 8 + 16 : 0);
+  const size_t o_g5peek = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth5 * (n < (1u << 23) ? 4 : 8) + 16 : 0);
   const bool sieve = gram && sieve_want;
   const size_t o_tri = blob_reserve (cur, sieve ? (size_t)gW * gW * 4 + 16 : 0);
   p->blob_bytes = cur;
@@ -915,6 +921,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     G.bloom5_bits = bloom5_bits;
     G.lo = fi.alpha_lo;
     G.kw_base = kw_base;
+    G.peek_packed = n < (1u << 23);
     fill_gram_tables (fv, fi, G);
   }
   if (dense) {
@@ -1022,9 +1029,10 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     if ((uint64_t)bits_bytes + gq + WALK_CTX_BYTES <= lds_total) {
       p->d_kw4 = u32p (o_kw4);
       p->GK.g4prefix = u32p (o_g4prefix);
-      p->GK.g4entry = reinterpret_cast<const uint4 *> (b + o_g4entry);
+      p->GK.g4entry = u32p (o_g4entry);
       p->GK.kw_inline = (uint64_t)fi.n_keywords + kw_base < HIT_KW4 ? 1u : 0u;
-      p->GK.g5peek = reinterpret_cast<const uint2 *> (b + o_g5peek);
+      p->GK.g5peek = u32p (o_g5peek);
+      p->GK.peek_packed = n < (1u << 23) ? 1u : 0u;
       p->GK.d5_begin = fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1];
       p->GK.bloom_off = bloom_off;
       p->GK.bloomT_bits = bloomT_bits;

@@ -65,14 +65,14 @@ struct GramK {
    * index (W^4 of them, 4.25 MB for a-z) did not fit beside the text streaming through: two of
    * three record gathers went to memory for a 128-byte line each, 5.5 x the algorithmic bytes. */
   const uint32_t *g4prefix;
-  const uint4 *g4entry;   /* by rank: {children mask | terminal << 31, state id of the first child, keyword id, -} */
+  const uint32_t *g4entry; /* by rank, 3 words: {children mask | terminal << 31, state id of the first child, keyword id} */
   uint32_t kw_inline;     /* keyword ids fit a hit's word beside HIT_KW4 (always, short of 2^30 keywords) */
   /* the walks start one level down, at the depth-5 state the 5th symbol leads to (children are
    * numbered consecutively in symbol order: first child + set mask bits below the class), and ask
    * g5peek[that state - d5_begin] = {its record, the symbol of its only edge | GRAM_NO_PEEK}
    * before any record: 708 KB that stay in L2 */
-  const uint2 *g5peek;
-  uint32_t d5_begin;
+  const uint32_t *g5peek; /* 4 bytes per state when peek_packed (record | symbol << 23 | GRAM_NO_PEEK's bit 31), else 8 */
+  uint32_t d5_begin, peek_packed;
   uint32_t R;             /* groups per tile */
   uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
 };
@@ -138,6 +138,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     Kc.remap = K.g4gid;
     Kc.remap_base = WIDE ? K.d4_begin : K.d5_begin;
     Kc.peek = K.g5peek;
+    Kc.peek_packed = K.peek_packed;
     *Ks = Kc;
     *Es = E;
   }
@@ -171,7 +172,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_items = 0, d_b1 = 0, d_cons = 0, d_tiles = 0;)
   uint2 pend_item[GRAM_DEPTH];
   uint32_t pend_rx[GRAM_DEPTH], pend_ry[GRAM_DEPTH], pend_rz[1] = { 0 }, pend_rw[1] = { 0 };
-  uint4 pend_e1 = make_uint4 (0, 0, 0, 0); /* the record's words, apart: a 64-bit register pair half in flight pins both (rz: narrow alphabets, the first child) */
+  uint3 pend_e1 = make_uint3 (0, 0, 0); /* the record's words, apart: a 64-bit register pair half in flight pins both (rz: narrow alphabets, the first child) */
   uint32_t pend_n[GRAM_DEPTH]; /* wave-uniform: items in each pending batch, [0] the oldest */
   constexpr uint32_t PEND_NEED = 0x80000000u;
 #pragma unroll
@@ -262,9 +263,9 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
                     "+v"(pend_item[1].x), "+v"(pend_item[1].y));
       __builtin_amdgcn_sched_barrier (0);
       const uint32_t rank = pend_rx[2] + (pend_ry[2] & ~PEND_NEED);
-      uint4 ent = make_uint4 (0, 0, 0, 0);
+      uint3 ent = make_uint3 (0, 0, 0);
       if (pend_n[1] && (pend_ry[2] & PEND_NEED))
-        ent = K.g4entry[rank];
+        ent = *reinterpret_cast<const uint3 *> (K.g4entry + 3 * (size_t)rank);
       pend_e1 = ent;
       pend_ry[1] = K.d4_begin + rank;
     }

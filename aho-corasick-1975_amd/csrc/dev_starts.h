@@ -39,7 +39,8 @@ struct StartsK {
   /* 4-gram kernel, narrow alphabets (walk_starts<.., 2>): an item without WI_RECORD names a
    * depth-5 state; peek[id - remap_base] = {its record, the symbol of its only edge or
    * GRAM_NO_PEEK} */
-  const uint2 *peek;
+  const uint32_t *peek;
+  uint32_t peek_packed; /* 4 bytes per state: record | symbol << 23 | "look at the record" << 31; else {record, symbol or GRAM_NO_PEEK} */
 };
 constexpr uint32_t ST_ALWAYS = 0x80000000u, ST_SECOND = 0x40000000u, ST_STATE = 0x3FFFFFFFu;
 
@@ -232,8 +233,13 @@ walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue
    * to be seen anyway); only record items touch the records */
   const bool fresh = GRAM == 2 && alive && !(it.y & WI_RECORD);
   uint2 pk = make_uint2 (0, 0);
-  if (fresh)
-    pk = K.peek[st - K.remap_base];
+  if (fresh) {
+    if (K.peek_packed) {
+      const uint32_t e = K.peek[st - K.remap_base];
+      pk = make_uint2 (e & 0x7FFFFFu, (e >> 31) ? GRAM_NO_PEEK : (e >> 23) & 0xFFu);
+    } else
+      pk = *reinterpret_cast<const uint2 *> (K.peek + 2 * (size_t)(st - K.remap_base));
+  }
   if (GRAM == 1 && !(it.y & WI_RECORD))
     st = alive ? K.remap[st - K.remap_base] : 0u;
   const bool regular = alive && !fresh;
