@@ -115,7 +115,10 @@ struct EmitCtx {
   uint32_t chain_base;
 };
 constexpr uint32_t HIT_LEN4 = 0x80000000u;
-constexpr uint32_t HIT_KW4 = 0x40000000u; /* the hit's word is the keyword id itself (a keyword of 4 symbols, id below 2^30) */
+/* the hit's word is the keyword itself: id (below 2^28) | length << 28 (1-3; 0: 4 symbols) | HIT_KW -- what
+ * the 4-gram kernel's tables hold for the keywords of up to 4 symbols, so that their records need
+ * no lookup (one in 13 positions of a text can end such a keyword) */
+constexpr uint32_t HIT_KW = 0x40000000u, HIT_KW_ID = 0x0FFFFFFFu;
 
 /* one launch: a segment of the buffer, positions relative to its first symbol */
 struct Launch {
@@ -484,6 +487,7 @@ struct GramImage {
   uint32_t *peek;                          /* narrow alphabets: per depth-5 state {its record, the symbol of its only edge or GRAM_NO_PEEK} */
   uint32_t *bloom;                         /* narrow alphabets: Bloom bits, terminal 4-grams then 5-grams (GramK::bloom5_bits; NULL: none) */
   uint32_t bloomT_bits, bloom5_bits, lo, kw_base;
+  bool kw_inline;                          /* keyword ids fit a hit's word (HIT_KW) */
   bool peek_packed;                        /* 4 bytes per depth-5 state (fewer than 2^23 records) instead of 8 */
   uint32_t *g3, *stab;                     /* short keywords: prefix states per 3-gram (narrow) / table of tagged windows (wide) */
 };
@@ -606,7 +610,7 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
       while (stab[2 * (size_t)slot + 1])
         slot = (slot + 1) & ((1u << G.stab_log2) - 1);
       stab[2 * (size_t)slot] = key;
-      stab[2 * (size_t)slot + 1] = st;
+      stab[2 * (size_t)slot + 1] = G.kw_inline ? (fv.term_kw[st] + G.kw_base) | (fv.depth[st] << 28) | HIT_KW : st;
     }
   }
   if (G.shorts && !G.wide) {
@@ -622,7 +626,7 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
         width *= G.W;
       for (uint32_t i3 = path[st] * width; i3 < (path[st] + 1) * width; i3++) {
         nib[i3 >> 1] |= (unsigned char)((1u << (d - 1)) << ((i3 & 1) * 4));
-        g3[4 * (size_t)i3 + (d - 1)] = st;
+        g3[4 * (size_t)i3 + (d - 1)] = G.kw_inline ? (fv.term_kw[st] + G.kw_base) | (d << 28) | HIT_KW : st;
       }
     }
   }
@@ -921,6 +925,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     G.bloom5_bits = bloom5_bits;
     G.lo = fi.alpha_lo;
     G.kw_base = kw_base;
+    G.kw_inline = (uint64_t)fi.n_keywords + kw_base <= HIT_KW_ID;
     G.peek_packed = n < (1u << 23);
     fill_gram_tables (fv, fi, G);
   }
@@ -1030,7 +1035,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
       p->d_kw4 = u32p (o_kw4);
       p->GK.g4prefix = u32p (o_g4prefix);
       p->GK.g4entry = u32p (o_g4entry);
-      p->GK.kw_inline = (uint64_t)fi.n_keywords + kw_base < HIT_KW4 ? 1u : 0u;
+      p->GK.kw_inline = (uint64_t)fi.n_keywords + kw_base <= HIT_KW_ID ? 1u : 0u;
       p->GK.g5peek = u32p (o_g5peek);
       p->GK.peek_packed = n < (1u << 23) ? 1u : 0u;
       p->GK.d5_begin = fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1];
@@ -2090,8 +2095,11 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     d_text = p->d_remap;
   }
   if (use_dense || (!COUNT_ONLY && (p->gram || p->starts))) {
-    /* 4-gram plans see dense matches (config 3: one per 38 symbols): room for one hit per 16 */
-    int rc = ensure_item_buffer (p, n < p->segment ? n : p->segment, p->gram && !p->sieve ? 16 : 256, use_dense ? DENSE_MIN_REGION_ITEMS : 256);
+    /* 4-gram plans see dense matches (config 3: one per 38 symbols): room for one hit per 16,
+     * per 8 when the dictionary has keywords of 1-3 symbols (12k keywords of 3-11 letters on
+     * random a-z text: one match per 13); past that a wave reserves records 64 at a time */
+    int rc = ensure_item_buffer (p, n < p->segment ? n : p->segment, p->gram && !p->sieve ? (p->gram_shorts ? 8 : 16) : 256,
+                                 use_dense ? DENSE_MIN_REGION_ITEMS : 256);
     if (rc)
       return rc;
   }

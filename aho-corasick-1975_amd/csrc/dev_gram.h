@@ -66,7 +66,7 @@ struct GramK {
    * three record gathers went to memory for a 128-byte line each, 5.5 x the algorithmic bytes. */
   const uint32_t *g4prefix;
   const uint32_t *g4entry; /* by rank, 3 words: {children mask | terminal << 31, state id of the first child, keyword id} */
-  uint32_t kw_inline;     /* keyword ids fit a hit's word beside HIT_KW4 (always, short of 2^30 keywords) */
+  uint32_t kw_inline;     /* keyword ids fit a hit's word beside HIT_KW (always, short of 2^28 keywords) */
   /* the walks start one level down, at the depth-5 state the 5th symbol leads to (children are
    * numbered consecutively in symbol order: first child + set mask bits below the class), and ask
    * g5peek[that state - d5_begin] = {its record, the symbol of its only edge | GRAM_NO_PEEK}
@@ -216,7 +216,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       const bool term = lane < pend_n[0] && (pend_rx[0] >> 31) && pend_item[0].x + 3 >= E.emit_from;
       /* (narrow alphabets: the entry brought the keyword's id along, and the hit carries it --
        * expand_hits_kernel spent 0.2 of its 0.52 ms per 2 GiB of config 3 on the gather by rank) */
-      const uint32_t what = (!WIDE && K.kw_inline) ? pend_rw[0] | HIT_KW4 : (pend_ry[0] - K.d4_begin) | HIT_LEN4;
+      const uint32_t what = (!WIDE && K.kw_inline) ? pend_rw[0] | HIT_KW : (pend_ry[0] - K.d4_begin) | HIT_LEN4;
       emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, what, lane, hits, counted);
       if (!COUNT_ONLY)
         counted = uniform ((uint32_t)counted);

@@ -63,15 +63,15 @@ hits_init (uint2 *hits, uint2 *region, uint32_t capacity, uint32_t lane) {
 }
 
 /* the record of a hit: (length, keyword id) of the terminal state it names -- its first output is
- * its own keyword -- or, for a keyword of 4 symbols found by a 4-gram kernel, the id the hit
- * carries (HIT_KW4) or (HIT_LEN4: the depth-4 state by rank) from the
+ * its own keyword -- or, for a keyword of 4 symbols found by a 4-gram kernel, the keyword the hit
+ * carries (HIT_KW) or (HIT_LEN4: the depth-4 state by rank) from the
  * small table of the depth-4 states */
 __device__ __forceinline__ void
 write_hit_record (const EmitCtx &E, uint2 h, unsigned long long slot) {
   uint32_t length, kw;
-  if (h.y & HIT_KW4) {
-    length = 4;
-    kw = h.y & ~HIT_KW4;
+  if (h.y & HIT_KW) {
+    length = (h.y >> 28) & 3u ? (h.y >> 28) & 3u : 4u;
+    kw = h.y & HIT_KW_ID;
   } else if (h.y & HIT_LEN4) {
     length = 4;
     kw = E.kw4[h.y & ~HIT_LEN4];
@@ -158,9 +158,10 @@ expand_hits_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint32
       length[u] = 4;
       kw[u] = 0;
       if (i < total && base + i < E.capacity) {
-        if (h[u].y & HIT_KW4)
-          kw[u] = h[u].y & ~HIT_KW4;
-        else if (h[u].y & HIT_LEN4)
+        if (h[u].y & HIT_KW) {
+          length[u] = (h[u].y >> 28) & 3u ? (h[u].y >> 28) & 3u : 4u;
+          kw[u] = h[u].y & HIT_KW_ID;
+        } else if (h[u].y & HIT_LEN4)
           kw[u] = E.kw4[h[u].y & ~HIT_LEN4];
         else {
           const uint4 oi = E.oinfo[h[u].y]; /* terminal state: its first output is its own keyword */
