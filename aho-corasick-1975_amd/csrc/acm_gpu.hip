@@ -851,7 +851,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
         tb = free_bits / 3;
       tb = tb / 128 * 128;
       const uint64_t fb = (free_bits - tb) / 128 * 128;
-      if (tb >= 1024 && fb >= (uint64_t)n_5 * 3 && fb < (1u << 24)) {
+      if (tb >= 1024 && fb >= (uint64_t)n_5 * 2 && fb < (1u << 24)) {
         bloomT_bits = (uint32_t)tb;
         bloom5_bits = (uint32_t)fb;
       }
