@@ -127,7 +127,10 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       dst[i] = src[i]; /* 4-gram bits, then (g3_off) the nibbles of the short keywords, then (bloom_off) the Bloom filters */
   }
   constexpr uint32_t NQ = SHORTS ? 3 : 2; /* queues per wave */
-  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (NQ * QCAP + HITS_STRIDE) * 8);
+  /* LDS queues per wave, 8-byte items: first queue (QCAP: up to 63 waiting + 64 from one position),
+   * walk queue (GRAM_Q2: up to 63 waiting + what one batch sends on, with room made first when
+   * that is more than 33), short-keyword queue (QCAP, SHORTS only), hit buffer */
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * ((NQ - 1) * QCAP + GRAM_Q2 + HITS_STRIDE) * 8);
   StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4); /* see scan_starts_kernel */
   EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
   if (threadIdx.x == 0) {
@@ -147,9 +150,9 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint32_t wib = uniform (threadIdx.x / WAVE);
   uint2 *q1 = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
-  uint2 *q2 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * QCAP;
-  uint2 *q3 = reinterpret_cast<uint2 *> (smem + K.queue_off) + 2 * WAVES * QCAP + wib * QCAP; /* SHORTS only */
-  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + NQ * WAVES * QCAP + wib * HITS_STRIDE + 2;
+  uint2 *q2 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * GRAM_Q2;
+  uint2 *q3 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * (QCAP + GRAM_Q2) + wib * QCAP; /* SHORTS only */
+  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * ((NQ - 1) * QCAP + GRAM_Q2) + wib * HITS_STRIDE + 2;
   const uint32_t wave_id = blockIdx.x * WAVES + wib;
   hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
   const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
@@ -228,6 +231,10 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       const bool pass = lane < pend_n[0] && ((pend_rx[0] >> (WIDE ? 0u : c4)) & 1u);
       const uint64_t m = __ballot (pass);
       if (m) {
+        /* (a walk call handles one level of the newest items and never leaves more than it took,
+         * and every item ends within lmax levels) */
+        while (qn2 + (uint32_t)__popcll (m) > GRAM_Q2)
+          walk_batch (qn2 < WAVE ? qn2 : WAVE);
         if (pass) {
           if (WIDE)
             q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 3, pend_ry[0] | WI_REPORTED);

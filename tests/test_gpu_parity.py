@@ -885,6 +885,28 @@ def test_gram_kernel_small_alphabet_dense_matches(torch_cuda):
         assert np.array_equal(got, want[(want["end_pos"] >= b) & (want["end_pos"] < e)]), (b, e)
 
 
+def test_gram_kernel_every_position_sends_a_walk(torch_cuda):
+    """The 4-gram kernel's queues at their limits: all rotations of a 10-letter string are keywords
+    and the text is that string over and over, so every position starts a keyword, every lane of
+    every batch passes both sieves, and 64 walk candidates arrive at a time (a walk queue of 96 has
+    to make room first); 12k random keywords of 4-9 letters beside them force the kernel."""
+    rng = np.random.default_rng(77)
+    base = np.frombuffer(b"abcdefghij", np.uint8)
+    kws = [np.roll(base, -k).copy() for k in range(base.size)]
+    kws += [rng.integers(97, 123, size=rng.integers(4, 10)).astype(np.uint8) for _ in range(12000)]
+    text = np.tile(base, 30000)
+    text[150000:150100] = rng.integers(97, 123, size=100)      # a break in the pattern
+    m, o = build_pair(kws, 1)
+    plan = m.plan(0)
+    assert plan.info.kernel == 5 and plan.info.dense_rows > 32768
+    want = o.scan(text)
+    assert want.size > text.size - 200
+    dev = _dev(torch_cuda, text)
+    got = plan.scan_sorted(dev)
+    assert got.size == want.size and np.array_equal(got, want)
+    assert int(plan.count(dev).item()) == want.size
+
+
 def _random_case(rng, kind):
     """Random dictionary + text meant for one kernel family; returns (keywords, text, sym_bytes, env)."""
     if kind == "dense":            # byte alphabet, few states: continuation-mode dense kernel
