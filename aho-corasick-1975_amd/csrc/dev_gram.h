@@ -175,7 +175,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_walk = 0, d_calls = 0, d_items = 0, d_b1 = 0, d_cons = 0, d_tiles = 0;)
   uint2 pend_item[GRAM_DEPTH];
   uint32_t pend_rx[GRAM_DEPTH], pend_ry[GRAM_DEPTH], pend_rz[1] = { 0 }, pend_rw[1] = { 0 };
-  uint3 pend_e1 = make_uint3 (0, 0, 0); /* the record's words, apart: a 64-bit register pair half in flight pins both (rz: narrow alphabets, the first child) */
+  uint3 pend_e1 = make_uint3 (0, 0, 0);
+  uint2 pend_w2 = make_uint2 (0, 0); /* wide alphabets: the newest batch's table slots */ /* the record's words, apart: a 64-bit register pair half in flight pins both (rz: narrow alphabets, the first child) */
   uint32_t pend_n[GRAM_DEPTH]; /* wave-uniform: items in each pending batch, [0] the oldest */
   constexpr uint32_t PEND_NEED = 0x80000000u;
 #pragma unroll
@@ -255,9 +256,14 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     pend_n[1] = pend_n[2];
     pend_n[2] = 0;
     if (WIDE) {
+      /* (the newest batch's table slots came in one 8-byte gather: a register pair that stays
+       * where it landed until its words are copied out here, one step later) */
       pend_rx[0] = pend_rx[1];
-      pend_rx[1] = pend_rx[2];
-      pend_ry[1] = pend_ry[2];
+      pend_rx[1] = pend_w2.x;
+      pend_ry[1] = pend_w2.y;
+      asm volatile ("" : "+v"(pend_rx[0]), "+v"(pend_ry[0]), "+v"(pend_rx[1]), "+v"(pend_ry[1]), "+v"(pend_item[0].x), "+v"(pend_item[0].y),
+                    "+v"(pend_item[1].x), "+v"(pend_item[1].y));
+      __builtin_amdgcn_sched_barrier (0);
     } else {
       /* the middle batch's entries came in one 16-byte gather (a register tuple: it stays where
        * it landed until its words are copied out here, one step later) */
@@ -292,9 +298,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     if constexpr (WIDE) {
       consume_oldest ();
       pend_item[GRAM_DEPTH - 1] = it;
-      const uint2 e = K.wtab[(it.y * WIDE_H2) >> (32 - K.wtab_log2)];
-      pend_rx[GRAM_DEPTH - 1] = e.x;
-      pend_ry[GRAM_DEPTH - 1] = e.y;
+      pend_w2 = K.wtab[(it.y * WIDE_H2) >> (32 - K.wtab_log2)];
     } else {
       consume_terminal ();
       const uint32_t idx = it.y & 0xFFFFFu, c5 = it.y >> 20;
