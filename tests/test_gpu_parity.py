@@ -122,6 +122,31 @@ def test_plan_with_delta_scans_counts_and_streams(torch_cuda, K):
     assert np.array_equal(plan.scan_sorted(dev), o.scan(text))
 
 
+def test_delta_plan_that_is_a_4gram_plan_itself(torch_cuda, monkeypatch):
+    """2,400 keywords added to a plan of 20,000: the delta is big enough for the 4-gram kernel, whose
+    tables hold keyword ids (hits that carry their keyword) -- they must be the machine's ids, i.e.
+    offset by the base plan's 20,000."""
+    monkeypatch.setenv("ACM_GPU_GRAM", "2")                    # (the 4-gram kernel whatever the size: the delta's too)
+    K, D = 20000, 2400
+    kd, ko = acm.synth.keywords(K + D)
+    m, o = build_pair_packed(kd[:ko[K]], ko[:K + 1], variant=po.MEYER85)
+    plan = m.plan(0)
+    assert plan.info.kernel == 5
+    for k in range(K, K + D):
+        w = kd[ko[k]:ko[k + 1]]
+        m.add_keyword(w)
+        o.add_keyword(w)
+    plan.update(m)
+    assert plan.info.merges == 0 and plan.info.delta_keywords == D
+    text = acm.synth.text(1 << 20, kd, ko)
+    want = o.scan(text)
+    new4 = want[(want["keyword_id"] >= K) & (want["length"] == 4)]
+    assert new4.size > 100                                     # 4-symbol keywords of the delta do match
+    dev = _dev(torch_cuda, text)
+    assert np.array_equal(plan.scan_sorted(dev), want)
+    assert int(plan.count(dev).item()) == want.size
+
+
 def _novel_words(novel_bytes):
     """generic_test.c:191-197: letters in lower case, everything else a blank"""
     t = np.frombuffer(novel_bytes, np.uint8).copy()
