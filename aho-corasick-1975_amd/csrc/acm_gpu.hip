@@ -837,7 +837,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const char *bloom_env = getenv ("ACM_GPU_BLOOM"); /* 0: no Bloom filters (experiments) */
   if (gram && !gram_wide && n_depth4 >= 2048 && !(bloom_env && atoi (bloom_env) == 0)) {
     const uint32_t lds_cap = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
-    const uint32_t gq_bytes = (SPARSE_THREADS / WAVE) * ((gram_shorts ? 2 : 1) * QCAP + GRAM_Q2 + HITS_STRIDE) * 8;
+    const uint32_t gq_bytes = (SPARSE_THREADS / WAVE) * ((gram_shorts ? 2 : 1) * QCAP + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
     bloom_off = (g3_off + g3_bytes + 15) & ~15u;
     const uint64_t used = (uint64_t)bloom_off + gq_bytes + WALK_CTX_BYTES + 64;
     uint32_t n_term4 = 0, n_5 = 0;
@@ -1030,7 +1030,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   p->d_dstart = u32p (o_dstart);
   if (gram) {
     const uint32_t lds_total = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
-    const uint32_t gq = (SPARSE_THREADS / WAVE) * ((gram_shorts ? 2 : 1) * QCAP + GRAM_Q2 + HITS_STRIDE) * 8;
+    const uint32_t gq = (SPARSE_THREADS / WAVE) * ((gram_shorts ? 2 : 1) * QCAP + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
     const uint32_t bits_bytes = bloom5_bits ? bloom_off + bloom_bytes : g3_off + g3_bytes;
     if ((uint64_t)bits_bytes + gq + WALK_CTX_BYTES <= lds_total) {
       p->d_kw4 = u32p (o_kw4);

@@ -129,8 +129,10 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   constexpr uint32_t NQ = SHORTS ? 3 : 2; /* queues per wave */
   /* LDS queues per wave, 8-byte items: first queue (QCAP: up to 63 waiting + 64 from one position),
    * walk queue (GRAM_Q2: up to 63 waiting + what one batch sends on, with room made first when
-   * that is more than 33), short-keyword queue (QCAP, SHORTS only), hit buffer */
-  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * ((NQ - 1) * QCAP + GRAM_Q2 + HITS_STRIDE) * 8);
+   * that is more than 33), short-keyword queue (QCAP, SHORTS only), hit buffer (wide alphabets) */
+  constexpr bool DIRECT = !WIDE; /* narrow alphabets: hits go straight to the wave's region, no LDS hit buffer */
+  constexpr uint32_t HB = DIRECT ? 0u : HITS_STRIDE;
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * ((NQ - 1) * QCAP + GRAM_Q2 + HB) * 8);
   StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4); /* see scan_starts_kernel */
   EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
   if (threadIdx.x == 0) {
@@ -142,6 +144,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     Kc.remap_base = WIDE ? K.d4_begin : K.d5_begin;
     Kc.peek = K.g5peek;
     Kc.peek_packed = K.peek_packed;
+    Kc.region_items = region_items;
     *Ks = Kc;
     *Es = E;
   }
@@ -152,9 +155,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   uint2 *q1 = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
   uint2 *q2 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * GRAM_Q2;
   uint2 *q3 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * (QCAP + GRAM_Q2) + wib * QCAP; /* SHORTS only */
-  uint2 *hits = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * ((NQ - 1) * QCAP + GRAM_Q2) + wib * HITS_STRIDE + 2;
   const uint32_t wave_id = blockIdx.x * WAVES + wib;
-  hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
+  uint2 *hits = DIRECT ? (COUNT_ONLY ? nullptr : items + (size_t)wave_id * region_items)
+                       : reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * ((NQ - 1) * QCAP + GRAM_Q2) + wib * HITS_STRIDE + 2;
+  if (!DIRECT)
+    hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
   const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
   /* block b takes the tiles b, b + gridDim.x, ... (match density is rarely even along a text:
    * contiguous shares left two blocks of config 3 working 1 ms after all others had finished),
@@ -200,6 +205,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   /* Second sieve on the oldest pending batch, in three parts so that a pipeline step can put the
    * LDS round trips of the NEW batch (its items, then its filter bits) behind them: a keyword of
    * 4 symbols ends here; the 5th symbol is an edge of the depth-4 state; the pipeline moves up. */
+  bool st_term = false;
+  uint32_t st_pos = 0, st_what = 0;
   auto consume_terminal = [&] () {
     if (pend_n[0]) {
       if (WIDE) {
@@ -220,11 +227,19 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       const bool term = lane < pend_n[0] && (pend_rx[0] >> 31) && pend_item[0].x + 3 >= E.emit_from;
       /* (narrow alphabets: the entry brought the keyword's id along, and the hit carries it --
        * expand_hits_kernel spent 0.2 of its 0.52 ms per 2 GiB of config 3 on the gather by rank) */
-      const uint32_t what = (!WIDE && K.kw_inline) ? pend_rw[0] | HIT_KW : (pend_ry[0] - K.d4_begin) | HIT_LEN4;
-      emit_terminals<COUNT_ONLY> (E, term, pend_item[0].x + 3, what, lane, hits, counted);
-      if (!COUNT_ONLY)
-        counted = uniform ((uint32_t)counted);
-    }
+      st_term = term;
+      st_pos = pend_item[0].x + 3;
+      st_what = (!WIDE && K.kw_inline) ? pend_rw[0] | HIT_KW : (pend_ry[0] - K.d4_begin) | HIT_LEN4;
+    } else
+      st_term = false;
+  };
+  /* (reported apart from the test: a pipeline step of the narrow kernel puts the store behind
+   * its gathers, so that the step's own wait for the older gathers does not wait for it) */
+  auto emit_stashed = [&] () {
+    emit_terminals<COUNT_ONLY, DIRECT> (E, st_term, st_pos, st_what, lane, hits, counted, Es, region_items);
+    if (!COUNT_ONLY)
+      counted = uniform ((uint32_t)counted);
+    st_term = false;
   };
   auto consume_pass = [&] () {
     if (pend_n[0]) {
@@ -285,6 +300,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   };
   auto consume_oldest = [&] () {
     consume_terminal ();
+    emit_stashed ();
     consume_pass ();
     pipeline_shift ();
   };
@@ -326,6 +342,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
         pre = K.g4prefix[idx >> 5];
       pend_rx[GRAM_DEPTH - 1] = pre;
       pend_ry[GRAM_DEPTH - 1] = __popc (word & ((1u << (idx & 31u)) - 1u)) | (need ? PEND_NEED : 0u);
+      emit_stashed ();
     }
     pend_n[GRAM_DEPTH - 1] = n_items;
   };
@@ -345,7 +362,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
         e = K.stab[slot];
       }
       const uint32_t end = it.x + (it.y >> 24) - 1;
-      emit_terminals<COUNT_ONLY> (E, valid && e.y != 0 && end >= E.emit_from, end, e.y, lane, hits, counted);
+      emit_terminals<COUNT_ONLY, DIRECT> (E, valid && e.y != 0 && end >= E.emit_from, end, e.y, lane, hits, counted, Es, region_items);
       if (!COUNT_ONLY)
         counted = uniform ((uint32_t)counted);
       return;
@@ -357,7 +374,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
 #pragma unroll
     for (uint32_t d = 0; d < 3; d++) {
       const bool hit = ((nib >> d) & 1u) && it.x + d >= E.emit_from;
-      emit_terminals<COUNT_ONLY> (E, hit, it.x + d, d == 0 ? rec.x : (d == 1 ? rec.y : rec.z), lane, hits, counted);
+      emit_terminals<COUNT_ONLY, DIRECT> (E, hit, it.x + d, d == 0 ? rec.x : (d == 1 ? rec.y : rec.z), lane, hits, counted, Es, region_items);
       if (!COUNT_ONLY)
         counted = uniform ((uint32_t)counted);
     }
@@ -540,10 +557,15 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     if (lane == 0 && total)
       atomicAdd (E.count, (unsigned long long)total);
   } else {
-    if (counted)
-      flush_hits (E, hits, (uint32_t)counted, lane);
-    if (lane == 0 && fill)
-      fill[wave_id] = hits[-1].y;
+    if (DIRECT) {
+      if (lane == 0 && fill)
+        fill[wave_id] = (uint32_t)counted;
+    } else {
+      if (counted)
+        flush_hits (E, hits, (uint32_t)counted, lane);
+      if (lane == 0 && fill)
+        fill[wave_id] = hits[-1].y;
+    }
   }
   DIAG (if (lane == 0 && wave_id < 8192) {
     unsigned long long *o = g_acm_diag[wave_id];

@@ -40,6 +40,7 @@ struct StartsK {
    * depth-5 state; peek[id - remap_base] = {its record, the symbol of its only edge or
    * GRAM_NO_PEEK} */
   const uint32_t *peek;
+  uint32_t region_items; /* walk_starts<.., 2>: hits go straight to the wave's region of this many items */
   uint32_t peek_packed; /* 4 bytes per state: record | symbol << 23 | "look at the record" << 31; else {record, symbol or GRAM_NO_PEEK} */
 };
 constexpr uint32_t ST_ALWAYS = 0x80000000u, ST_SECOND = 0x40000000u, ST_STATE = 0x3FFFFFFFu;
@@ -181,11 +182,31 @@ expand_hits_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint32
   }
 }
 
+/* the wave's region is full and there is no LDS buffer in between (DIRECT): this batch's hits as
+ * records straight from the registers, one atomic for all of them (rare, out of line) */
+__device__ __noinline__ void
+emit_overflow (const EmitCtx *Ep, bool hit, uint32_t p, uint32_t st) {
+  const EmitCtx &E = *Ep;
+  const uint64_t m = __ballot (hit);
+  const uint32_t total = (uint32_t)__popcll (m);
+  unsigned long long slot = 0;
+  if (lane_id () == 0)
+    slot = atomicAdd (E.count, (unsigned long long)total);
+  slot = ((unsigned long long)__shfl ((uint32_t)(slot >> 32), 0, WAVE) << 32) | __shfl ((uint32_t)slot, 0, WAVE);
+  slot += rank_below (m);
+  if (hit && slot < E.capacity)
+    write_hit_record (E, make_uint2 (p, st), slot);
+}
+
 /* tally: this lane's finds (count-only mode; summed over the wave at the end of the kernel) or
- * the fill of the hit buffer (record mode, wave-uniform) */
-template <bool COUNT_ONLY>
+ * the fill of the hit buffer (record mode, wave-uniform).  DIRECT (4-gram kernel, narrow
+ * alphabets): no LDS buffer -- `hits` is the wave's region of the item buffer itself, the tally
+ * its fill, a hit a plain store (what one batch reports lies side by side); Ep = the LDS copy of
+ * E for the out-of-line overflow path. */
+template <bool COUNT_ONLY, bool DIRECT = false>
 __device__ __forceinline__ void
-emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t lane, uint2 *hits, unsigned long long &tally) {
+emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t lane, uint2 *hits, unsigned long long &tally,
+                const EmitCtx *Ep = nullptr, uint32_t capacity = 0) {
   if (COUNT_ONLY) {
     tally += hit ? 1u : 0u;
     return;
@@ -194,6 +215,15 @@ emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t la
   if (m) {
     const uint32_t total = (uint32_t)__popcll (m);
     uint32_t hn = (uint32_t)tally;
+    if (DIRECT) {
+      if (hn + total <= capacity) {
+        if (hit)
+          hits[hn + rank_below (m)] = make_uint2 (p, st);
+        tally = hn + total;
+      } else
+        emit_overflow (Ep, hit, p, st);
+      return;
+    }
     if (hn + total > WAVE) {
       flush_hits (E, hits, hn, lane);
       hn = 0;
@@ -251,8 +281,8 @@ walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue
   }
   const bool more = alive && p + 1 < E.n;
   const uint32_t c1 = more ? (uint32_t)text[p + 1] : 0u;
-  emit_terminals<COUNT_ONLY> (E, regular && !(it.y & WI_REPORTED) && ra.w != 0 && p >= E.emit_from, p, GRAM ? ra.x : st, lane, hits,
-                              counted);
+  emit_terminals<COUNT_ONLY, GRAM == 2> (E, regular && !(it.y & WI_REPORTED) && ra.w != 0 && p >= E.emit_from, p, GRAM ? ra.x : st, lane,
+                                         hits, counted, Ep, K.region_items);
   uint32_t nx = NONE;
   if (more && regular) {
     const uint32_t ne = ra.y;

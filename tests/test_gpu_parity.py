@@ -919,7 +919,7 @@ def test_gram_kernel_every_position_sends_a_walk(torch_cuda):
     base = np.frombuffer(b"abcdefghij", np.uint8)
     kws = [np.roll(base, -k).copy() for k in range(base.size)]
     kws += [rng.integers(97, 123, size=rng.integers(4, 10)).astype(np.uint8) for _ in range(12000)]
-    text = np.tile(base, 30000)
+    text = np.tile(base, 120000)                               # (a match per position: more than a wave's region of the item buffer holds)
     text[150000:150100] = rng.integers(97, 123, size=100)      # a break in the pattern
     m, o = build_pair(kws, 1)
     plan = m.plan(0)
