@@ -870,7 +870,9 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const size_t o_g4prefix = blob_reserve (cur, gram && !gram_wide ? (size_t)g4words * 4 + 16 : 0);
   const size_t o_g4entry = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth4 * 12 + 16 : 0);
   const uint32_t n_depth5 = gram && fi.lmax >= 5 ? fv.depth_start[6 <= fi.lmax + 1 ? 6 : fi.lmax + 1] - fv.depth_start[5] : 0;
-  const size_t o_g5peek = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth5 * (n < (1u << 23) ? 4 : 8) + 16 : 0);
+  /* peek entries of 4 bytes while a record index fits 23 bits (ACM_GPU_PEEK8=1: 8 bytes anyway -- tests) */
+  const bool peek_packed = n < (1u << 23) && !(getenv ("ACM_GPU_PEEK8") && atoi (getenv ("ACM_GPU_PEEK8")) == 1);
+  const size_t o_g5peek = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth5 * (peek_packed ? 4 : 8) + 16 : 0);
   const bool sieve = gram && sieve_want;
   const size_t o_tri = blob_reserve (cur, sieve ? (size_t)gW * gW * 4 + 16 : 0);
   p->blob_bytes = cur;
@@ -927,7 +929,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     G.lo = fi.alpha_lo;
     G.kw_base = kw_base;
     G.kw_inline = (uint64_t)fi.n_keywords + kw_base <= HIT_KW_ID;
-    G.peek_packed = n < (1u << 23);
+    G.peek_packed = peek_packed;
     fill_gram_tables (fv, fi, G);
   }
   if (dense) {
@@ -1038,7 +1040,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
       p->GK.g4entry = u32p (o_g4entry);
       p->GK.kw_inline = (uint64_t)fi.n_keywords + kw_base <= HIT_KW_ID ? 1u : 0u;
       p->GK.g5peek = u32p (o_g5peek);
-      p->GK.peek_packed = n < (1u << 23) ? 1u : 0u;
+      p->GK.peek_packed = peek_packed ? 1u : 0u;
       p->GK.d5_begin = fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1];
       p->GK.bloom_off = bloom_off;
       p->GK.bloomT_bits = bloomT_bits;

@@ -1010,6 +1010,8 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
         monkeypatch.setenv(k, v)
     if seed == 2:   # launch segments of 8 Ki symbols instead of 2^31: every kernel family across many seams
         monkeypatch.setenv("ACM_GPU_SEGMENT_LOG2", "13")
+    if seed == 1:   # the 4-gram kernel's peek entries in their 8-byte form (automata of 8 M states and more)
+        monkeypatch.setenv("ACM_GPU_PEEK8", "1")
     # plant some keywords so that long matches exist
     for _ in range(min(200, text.size // 50)):
         w = kws[int(rng.integers(0, len(kws)))]
