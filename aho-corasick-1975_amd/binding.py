@@ -58,7 +58,8 @@ class FlatView(C.Structure):
 class PlanInfo(C.Structure):
     _fields_ = [("device", C.c_int)] + [(n, C.c_uint32) for n in (
         "kernel", "entry_bytes", "width", "dense_rows", "lds_rows", "lds_hotfail", "lds_bytes", "block_threads", "grid_blocks",
-        "chunk_bytes", "streams")] + [("table_bytes", C.c_uint64), ("delta_keywords", C.c_uint32), ("merges", C.c_uint32)]
+        "chunk_bytes", "streams")] + [("table_bytes", C.c_uint64), ("delta_keywords", C.c_uint32), ("merges", C.c_uint32),
+                                     ("records_direct", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _lib = None
@@ -73,8 +74,10 @@ EXPORTS = [
     "acm_flat_load", "acm_flat_keyword", "acm_flatten_classes", "acm_gpu_plan_create_classes", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_update", "acm_gpu_plan_destroy",
     "acm_gpu_plan_info", "acm_gpu_scan_device", "acm_gpu_count_device", "acm_gpu_sort_tmp_bytes",
     "acm_gpu_sort_records_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
-    "acm_gpu_plan_timing_read", "acm_gpu_plan_status", "acm_gpu_synth_text",
+    "acm_gpu_plan_timing_read", "acm_gpu_plan_timing_read_all", "acm_gpu_plan_status", "acm_gpu_synth_text",
     "acm_gpu_stream_open", "acm_gpu_stream_feed", "acm_gpu_stream_finish", "acm_gpu_stream_close",
+    "acm_gpu_multi_create", "acm_gpu_multi_destroy", "acm_gpu_multi_shard_bounds", "acm_gpu_multi_scan_host",
+    "acm_gpu_multi_scan_device",
 ]
 
 
@@ -180,6 +183,18 @@ def lib():
     L.acm_gpu_plan_timing.argtypes = [vp, i32]
     L.acm_gpu_plan_timing_read.restype = i32
     L.acm_gpu_plan_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.acm_gpu_multi_create.restype = i32
+    L.acm_gpu_multi_create.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.acm_gpu_multi_destroy.restype = None
+    L.acm_gpu_multi_destroy.argtypes = [vp]
+    L.acm_gpu_multi_shard_bounds.restype = i32
+    L.acm_gpu_multi_shard_bounds.argtypes = [vp, u64, C.c_int, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.acm_gpu_multi_scan_host.restype = i32
+    L.acm_gpu_multi_scan_host.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    L.acm_gpu_multi_scan_device.restype = i32
+    L.acm_gpu_multi_scan_device.argtypes = [vp, C.POINTER(vp), u64, vp, u64, C.POINTER(u64)]
+    L.acm_gpu_plan_timing_read_all.restype = i32
+    L.acm_gpu_plan_timing_read_all.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(u64)]
     L.acm_gpu_synth_text.restype = i32
     L.acm_gpu_synth_text.argtypes = [i32, vp, u64, u64, u32, u32, vp, vp, u32, vp]
     _lib = L
@@ -552,6 +567,66 @@ class Plan:
         ms, n = C.c_double(0), C.c_uint64(0)
         _check(lib().acm_gpu_plan_timing_read(self.h, C.byref(ms), C.byref(n)), "acm_gpu_plan_timing_read")
         return ms.value, int(n.value)
+
+    def timing_read_all(self):
+        """(scan kernels' ms, ms from each scan kernel's start to the end of its expansion /
+        hole-closing kernel, launches) since timing(True)."""
+        ms, allms, n = C.c_double(0), C.c_double(0), C.c_uint64(0)
+        _check(lib().acm_gpu_plan_timing_read_all(self.h, C.byref(ms), C.byref(allms), C.byref(n)), "acm_gpu_plan_timing_read_all")
+        return ms.value, allms.value, int(n.value)
+
+
+class MultiScan:
+    """acm_gpu_multi_*: one process, shard r of a text on devices[r] (a device may repeat), the
+    ordered records gathered on devices[0] by peer copies -- the C caller's way to use the GPUs of
+    a node (include/acm_gpu.h); torch.distributed jobs use sharded.py instead."""
+
+    def __init__(self, machine, devices):
+        self.devices = list(devices)
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        _check(lib().acm_gpu_multi_create(machine.handle, arr, len(self.devices), C.byref(h)), "acm_gpu_multi_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().acm_gpu_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard_bounds(self, n_symbols, shard):
+        rb, b, e = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().acm_gpu_multi_shard_bounds(self.h, n_symbols, shard, C.byref(rb), C.byref(b), C.byref(e)), "acm_gpu_multi_shard_bounds")
+        return int(rb.value), int(b.value), int(e.value)
+
+    def scan_host(self, text, capacity=None):
+        """numpy text in host memory -> records of the whole text in canonical order (numpy)."""
+        t = np.ascontiguousarray(text)
+        n = t.size
+        cap = int(capacity) if capacity is not None else max(n // 16, 1024)
+        while True:
+            out = np.zeros(cap, dtype=RECORD_DTYPE)
+            found = C.c_uint64(0)
+            rc = lib().acm_gpu_multi_scan_host(self.h, t.ctypes.data, n, out.ctypes.data, cap, C.byref(found))
+            if rc == -4 and capacity is None:       # ACM_GPU_E_OVERFLOW: the call says how many there are
+                cap = int(found.value)
+                continue
+            _check(rc, "acm_gpu_multi_scan_host")
+            return out[:found.value]
+
+    def scan_device(self, shard_tensors, n_symbols, records):
+        """shard_tensors[r]: torch tensor on devices[r] holding [read_begin_r, own_end_r); records:
+        int64 [cap, 2] tensor on devices[0].  Returns the number of records (all of the text's)."""
+        ptrs = (C.c_void_p * len(shard_tensors))(*[int(t.data_ptr()) for t in shard_tensors])
+        found = C.c_uint64(0)
+        _check(lib().acm_gpu_multi_scan_device(self.h, ptrs, n_symbols, records.data_ptr(), records.shape[0], C.byref(found)),
+               "acm_gpu_multi_scan_device")
+        return int(found.value)
 
 
 class Stream:

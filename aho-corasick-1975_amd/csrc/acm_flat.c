@@ -126,7 +126,9 @@ acm_flat_release (ACMFlat *f) {
 
 /* class_map != NULL: symbols are replaced by their comparator class (ownership of class_map
  * passes to the flat tables on success) */
-/* class of symbol v among the n sorted keys (it is one of them) */
+/* class of symbol v among the n sorted keys; UINT32_MAX if it is not one of them (a keyword that
+ * came in between the walk that collected the keys and the snapshot that asks: flatten_classes32
+ * starts over) */
 static uint32_t
 key32_class (const uint32_t *keys, const uint32_t *classes, uint32_t n, uint32_t v) {
   uint32_t lo = 0, hi = n;
@@ -137,8 +139,9 @@ key32_class (const uint32_t *keys, const uint32_t *classes, uint32_t n, uint32_t
     else
       hi = mid;
   }
-  return classes[lo];
+  return n && keys[lo] == v ? classes[lo] : UINT32_MAX;
 }
+#define ACM_FLAT_STALE_KEYS (-1000) /* internal: flatten_impl met a symbol the key table does not hold */
 
 struct keys32_arg {
   uint32_t *keys, *classes, *reps;
@@ -175,6 +178,7 @@ flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint3
 
   /* breadth-first renumbering; the queue is `order` itself */
   uint32_t head = 0, tail = 0, edges = 0, lmax = 0, nkw = 0, max_out = 0;
+  int stale_keys = 0;
   order[tail++] = acm_internal_root (machine);
   newid[order[0]->id] = 0;
   if (sym_bytes == 8) {
@@ -213,6 +217,7 @@ flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint3
       } else if (k32) {
         f->edge_letter[edges] = f->edge_sym[edges];
         f->edge_sym[edges] = key32_class (k32->keys, k32->classes, k32->n, f->edge_sym[edges]);
+        stale_keys |= f->edge_sym[edges] == UINT32_MAX;
       }
       f->edge_next[edges] = tail;
       edges++;
@@ -229,6 +234,13 @@ flatten_impl (ACMachine *machine, uint32_t sym_bytes, uint16_t *class_map, uint3
     head++;
   }
   f->row_ptr[n] = edges;
+  if (stale_keys) { /* never hand out tables in which a symbol took a neighbour's class */
+    acm_internal_unlock (machine);
+    free (order);
+    free (newid);
+    acm_flat_release (f);
+    return ACM_FLAT_STALE_KEYS;
+  }
 
   uint32_t lo = UINT32_MAX, hi = 0;
   for (uint32_t e = 0; e < edges; e++) {
@@ -369,7 +381,7 @@ key_class_cmp (const void *a, const void *b) {
 }
 
 static int
-flatten_classes32 (ACMachine *machine, ACMFlat **out) {
+flatten_classes32_once (ACMachine *machine, ACMFlat **out) {
   struct sym32_ctx ctx;
   acm_internal_comparator (machine, &ctx.cmp, &ctx.arg);
   /* every letter of the dictionary: one per state but the root (duplicates go away below) */
@@ -454,8 +466,8 @@ flatten_classes32 (ACMachine *machine, ACMFlat **out) {
     k32.classes[i] = kc[i].cls;
   }
   free (kc);
-  /* (a keyword inserted between the walk above and the snapshot below would bring a symbol without
-   * a class: the caller holds the dictionary still, as for every flatten of a plan it then uses) */
+  /* (a keyword inserted between the walk above and the snapshot below can bring a symbol without a
+   * class: flatten_impl notices and the caller below starts over) */
   int rc = flatten_impl (machine, 4, NULL, 0, 0, out, &k32);
   if (rc) {
     free (k32.keys);
@@ -463,6 +475,19 @@ flatten_classes32 (ACMachine *machine, ACMFlat **out) {
     free (reps);
   }
   return rc;
+}
+
+static int
+flatten_classes32 (ACMachine *machine, ACMFlat **out) {
+  /* the symbols are collected under one hold of the machine's lock and the snapshot is taken under
+   * the next: an insertion in between that brings a new symbol makes the snapshot stale -- again,
+   * a few times; a dictionary that keeps growing new symbols faster than that is not flattened */
+  for (int attempt = 0; attempt < 8; attempt++) {
+    const int rc = flatten_classes32_once (machine, out);
+    if (rc != ACM_FLAT_STALE_KEYS)
+      return rc;
+  }
+  return ACM_GPU_E_INELIGIBLE;
 }
 
 int

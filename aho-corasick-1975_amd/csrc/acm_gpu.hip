@@ -15,9 +15,6 @@
  *                                     mode with rows in HBM for bigger dictionaries
  *   dev_gram.h    scan_gram_kernel    byte alphabets, big dictionaries of keywords >= 4 symbols:
  *                                     4-gram bit table in LDS, every position tested on its own
- *   dev_sieve.h   scan_sieve_kernel   byte alphabets, small dictionaries of keywords >= 4 symbols
- *                                     (config 2: the headline kernel): trigram bits once per LDS
- *                                     bank, one conflict-free ds_read_b32 per symbol
  *   dev_starts.h  scan_starts_kernel  2- and 4-byte symbols: root table by symbol value in LDS,
  *                                     every position tested on its own; walk_starts, hit parking
  *   dev_sparse.h  scan_sparse_kernel  2- and 4-byte symbols, automaton walk (ACM_GPU_SPARSE=walk)
@@ -114,6 +111,11 @@ struct EmitCtx {
    * s is a leaf.  NULL: none. */
   const uint4 *chain;
   uint32_t chain_base;
+  /* 4-gram kernel, narrow alphabets: records are written by the scan kernel itself into chunks of
+   * the caller's buffer (dev_starts.h: WaveRec); slots past `capacity` go to the plan's spill
+   * area, from which close_holes_kernel brings them back into the holes below the dense count */
+  uint4 *spill;
+  uint64_t spill_slots;
 };
 constexpr uint32_t HIT_LEN4 = 0x80000000u;
 /* the hit's word is the keyword itself: id (below 2^28) | length << 28 (1-3; 0: 4 symbols) | HIT_KW -- what
@@ -130,6 +132,7 @@ struct Launch {
   /* dense: tiles [range_begin, static_end) are split evenly between the blocks; [static_end,
    * range_end) is a pool in POOL_CLASSES equal parts, handed out tile by tile through pool_ctr */
   uint32_t static_end, pool_class_tiles;
+  uint32_t pool_classes; /* min (POOL_CLASSES, blocks): block b draws from part b * pool_classes / blocks */
   unsigned int *pool_ctr, *pool_reset; /* this launch's counters; the previous launch's, to zero */
 };
 static constexpr uint32_t POOL_CLASSES = 16, POOL_CTR_STRIDE = 64; /* counters 256 B apart */
@@ -155,7 +158,6 @@ constexpr uint32_t IT_OUT = 1u << 29;   /* report the outputs of the state itsel
 #include "dev_sparse.h"
 #include "dev_starts.h"
 #include "dev_gram.h"
-#include "dev_sieve.h"
 #include "dev_misc.h"
 
 } // namespace
@@ -214,9 +216,6 @@ struct ACMPlan {
   StartsMirror *mir = nullptr; /* starts plans: what acm_gpu_plan_update edits */
   GramK GK{};
   bool gram = false; /* 4-gram sieve kernel instead of the sticky dense walk */
-  SieveK VK{};
-  bool sieve = false; /* trigram sieve kernel in front of the 4-gram kernel's later stages */
-  uint32_t sieve_lds_bytes = 0;
   bool gram_shorts = false, gram_wide = false;
   uint32_t gram_lds_bytes = 0;
   uint32_t class_sym_bytes = 0; /* comparator-class plans: the symbol size they were made for */
@@ -254,11 +253,20 @@ struct ACMPlan {
   void *cmp32_arg = nullptr;
   unsigned long long *d_cls32 = nullptr;
   uint32_t cls32_slots = 0, cls32_uploaded = 0; /* table size; known symbols it holds */
-  uint32_t *d_unknown = nullptr; /* [0] count, [1 ..] symbols */
-  static constexpr uint32_t CLS32_UNKNOWN_CAP = 1u << 16;
+  uint32_t *d_unknown = nullptr; /* [0] count, [1 .. cls32_cap] symbols */
+  /* symbols one pass can hand to the host: doubled (up to CLS32_CAP_MAX) whenever a pass fills the
+   * list, so that a text of many distinct symbols takes a few passes, not one per 65,536 of them;
+   * the plan refuses texts that bring more than CLS32_KNOWN_MAX distinct symbols in all (the host
+   * map and the device table hold every one of them) */
+  static constexpr uint32_t CLS32_CAP_MIN = 1u << 16, CLS32_CAP_MAX = 1u << 22, CLS32_KNOWN_MAX = 1u << 25;
+  uint32_t cls32_cap = CLS32_CAP_MIN;
   void *d_remap = nullptr;
   size_t remap_bytes = 0;
   uint32_t regions = 0, region_items = 0;
+  /* 4-gram kernel, narrow alphabets (records straight from the scan kernel): one hole descriptor
+   * per wave and the spill area, one chunk of records per wave (64 MB on 256 CUs) */
+  void *d_holes = nullptr, *d_spill = nullptr;
+  uint32_t direct_regions = 0;
   uint64_t segment = SEGMENT;
   uint64_t generation = 0; /* for the machine-cached plan */
   /* Dictionary growth without a rebuild (acm_gpu_plan_update): the keywords a machine got after
@@ -276,20 +284,15 @@ struct ACMPlan {
     hipEvent_t done; /* nullptr until the first scan after the retirement has recorded it */
   };
   std::vector<Retired> retired;
-  /* ACM_GPU_EXPAND (experiments): 2 = expand_items_once_kernel, one atomic per block (default:
-   * config 2 step 0.3202 -> 0.3182 ms); 0 = expand_items_kernel, one atomic per round of 1024
-   * items.  (Tried: no parking at all, every wave expanding its own queue inside the scan kernel:
-   * 0.277 -> 0.427 ms on the scan kernel, the walks stall the wave; smaller blocks -- 512 x 8
-   * regions, 256 x 4, 256 x 2, with 2 or 4 rounds in registers -- 44 to 77 us against 39: every
-   * block costs two atomics on one line; warming the L2s with the continuation rows and output
-   * records at the start of the kernel: 1 us.) */
-  int expand_mode = 2;
   int cu_count = 0;
   /* timing */
   bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  struct LaunchEvents {
+    hipEvent_t start, scan_done, all_done; /* around the scan kernel; after what follows it (expansion / hole closing) */
+  };
+  std::vector<LaunchEvents> events;
   size_t events_used = 0;
-  double timing_ms = 0;
+  double timing_ms = 0, timing_all_ms = 0;
   uint64_t timing_launches = 0;
 };
 
@@ -483,7 +486,6 @@ struct GramImage {
   uint32_t W, bloom_log2, wtab_log2, stab_log2;
   uint32_t *bits, *g4, *rec, *edge, *g4gid; /* first-stage bits, second-stage records, trie records (depth-first), their edges, depth-4 state -> record */
   unsigned char *nib;                      /* narrow alphabets: nibble per 3-gram */
-  uint32_t *tri;                           /* trigram sieve kernel: [W * W] words, bit c2 of word c0 * W + c1 (NULL: not wanted) */
   uint32_t *prefix, *entry;                /* narrow alphabets: set bits before each word of `bits`; by rank {children mask | terminal << 31, first child's state id, keyword id} */
   uint32_t *peek;                          /* narrow alphabets: per depth-5 state {its record, the symbol of its only edge or GRAM_NO_PEEK} */
   uint32_t *bloom;                         /* narrow alphabets: Bloom bits, terminal 4-grams then 5-grams (GramK::bloom5_bits; NULL: none) */
@@ -519,9 +521,9 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
       const uint32_t b0 = fv.row_ptr[st], ne = fv.row_ptr[st + 1] - b0;
       uint32_t *r = rec + 8 * (size_t)gid[st];
       r[0] = st;
-      r[1] = ne;
+      r[1] = ne | (fv.depth[st] << 16); /* (byte alphabet: at most 256 edges; depth < 4,096: the dense eligibility test) */
       r[2] = slots;
-      r[3] = fv.term_kw[st] != NONE ? 1u : 0u;
+      r[3] = fv.term_kw[st] != NONE ? fv.term_kw[st] + G.kw_base + 1u : 0u; /* terminal: keyword id + 1 (a record written on the spot needs it) */
       r[4] = ne >= 1 ? fv.edge_sym[b0] : 0;
       r[5] = ne >= 1 ? gid[fv.edge_next[b0]] : 0;
       r[6] = ne >= 2 ? fv.edge_sym[b0 + 1] : 0;
@@ -555,8 +557,6 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
       path[fv.edge_next[e]] = G.wide ? path[st] | (fv.edge_sym[e] << (8 * fv.depth[st])) /* the 4 bytes as the text holds them */
                                         : path[st] * G.W + (fv.edge_sym[e] - fi.alpha_lo);
-  for (uint32_t st = fv.depth_start[3]; G.tri && st < fv.depth_start[4]; st++)
-    G.tri[path[st] / G.W] |= 1u << (path[st] % G.W);
   for (uint32_t st = fv.depth_start[4]; G.wide && st < fv.depth_start[5]; st++) {
     const uint32_t win = path[st];
     const uint32_t hb = (win * WIDE_H1) >> (32 - G.bloom_log2);
@@ -627,7 +627,7 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
         width *= G.W;
       for (uint32_t i3 = path[st] * width; i3 < (path[st] + 1) * width; i3++) {
         nib[i3 >> 1] |= (unsigned char)((1u << (d - 1)) << ((i3 & 1) * 4));
-        g3[4 * (size_t)i3 + (d - 1)] = G.kw_inline ? (fv.term_kw[st] + G.kw_base) | (d << 28) | HIT_KW : st;
+        g3[4 * (size_t)i3 + (d - 1)] = fv.term_kw[st] + G.kw_base; /* the keyword's id: its record is written on the spot */
       }
     }
   }
@@ -698,8 +698,6 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   p->text_sym_bytes = interned ? 8 : fi.sym_bytes;
   p->cu_count = prop.multiProcessorCount;
 
-  if (const char *e = getenv ("ACM_GPU_EXPAND"))
-    p->expand_mode = atoi (e);
   if (const char *e = getenv ("ACM_GPU_SEGMENT_LOG2")) {
     const int lg = atoi (e);
     if (lg >= 12 && lg <= 31)
@@ -788,21 +786,10 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
       rowless_share += pow ((double)fi.alpha_span, -(double)fv.depth[s]);
   }
   const bool gram_narrow = fi.width <= 30 && fi.width == fi.alpha_span + 1 && gram_mode != 3; /* 3: hashed windows always (experiments) */
-  /* trigram sieve kernel (dev_sieve.h): narrow alphabets, every keyword of 4 symbols or more, and
-   * a trigram set thin enough to be a sieve (config 2: 5 % of the W^3 trigrams; above 12 % the
-   * candidates would swamp its second stage).  Only with ACM_GPU_SIEVE=1: measured SLOWER than the
-   * dense kernel on config 2 (0.63 against 0.28 ms per GiB; its first stage alone, candidates only
-   * counted, takes the dense kernel's 0.28 ms: both are bound by VALU issue -- a wave64 integer
-   * instruction holds its SIMD for 4 cycles, and either kernel needs ~6 of them per symbol -- not
-   * by the LDS lookups the sieve makes conflict-free). */
   bool any_short = false;
   for (uint32_t k = 0; k < fi.n_keywords; k++)
     any_short |= fv.depth[fv.kw_state[k]] < 4;
-  const char *sieve_env = getenv ("ACM_GPU_SIEVE");
-  const bool sieve_want = dense && gram_narrow && gram_mode != 0 && sieve_env && atoi (sieve_env) == 1 && fi.lmax >= 4 && !any_short &&
-                          n < 0x40000000u && fi.n_keywords > 0 &&
-                          (double)(fv.depth_start[4] - fv.depth_start[3]) <= 0.12 * (double)fi.width * fi.width * fi.width;
-  const bool gram_big = dense && (entry_bytes == 4 || gram_mode >= 2 || rowless_share > 0.001 || sieve_want) && gram_mode != 0 &&
+  const bool gram_big = dense && (entry_bytes == 4 || gram_mode >= 2 || rowless_share > 0.001) && gram_mode != 0 &&
                         fi.lmax >= 4 && n < 0x40000000u;
   bool gram_shorts = gram_big && any_short; /* keywords of 1-3 symbols: the kernel's nibble table and third queue */
   /* wide alphabets: hashed 4-byte windows instead of the exact base-W index */
@@ -873,8 +860,6 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   /* peek entries of 4 bytes while a record index fits 23 bits (ACM_GPU_PEEK8=1: 8 bytes anyway -- tests) */
   const bool peek_packed = n < (1u << 23) && !(getenv ("ACM_GPU_PEEK8") && atoi (getenv ("ACM_GPU_PEEK8")) == 1);
   const size_t o_g5peek = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth5 * (peek_packed ? 4 : 8) + 16 : 0);
-  const bool sieve = gram && sieve_want;
-  const size_t o_tri = blob_reserve (cur, sieve ? (size_t)gW * gW * 4 + 16 : 0);
   p->blob_bytes = cur;
 
   std::vector<unsigned char> host (cur, 0);
@@ -919,7 +904,6 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     G.stab = reinterpret_cast<uint32_t *> (&host[o_stab]);
     for (uint32_t st = fv.depth_start[4]; st < fv.depth_start[5]; st++)
       reinterpret_cast<uint32_t *> (&host[o_kw4])[st - fv.depth_start[4]] = fv.term_kw[st] == NONE ? NONE : fv.term_kw[st] + kw_base;
-    G.tri = sieve ? reinterpret_cast<uint32_t *> (&host[o_tri]) : nullptr;
     G.prefix = reinterpret_cast<uint32_t *> (&host[o_g4prefix]);
     G.entry = reinterpret_cast<uint32_t *> (&host[o_g4entry]);
     G.peek = gram_wide ? nullptr : reinterpret_cast<uint32_t *> (&host[o_g5peek]);
@@ -1071,16 +1055,6 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
       p->GK.queue_off = bits_bytes;
       p->gram_lds_bytes = bits_bytes + gq + WALK_CTX_BYTES;
     }
-    const uint32_t tri_bytes = gW * gW * 128u; /* every word once per bank of a lane group */
-    const uint32_t sq = (SPARSE_THREADS / WAVE) * (2 * QCAP + HITS_STRIDE) * 8;
-    if (p->gram && sieve && (uint64_t)tri_bytes + sq + WALK_CTX_BYTES <= lds_total) {
-      p->sieve = true;
-      p->VK.G = p->GK;
-      p->VK.G.queue_off = tri_bytes;
-      p->VK.tri = u32p (o_tri);
-      p->VK.tri_words = gW * gW;
-      p->sieve_lds_bytes = tri_bytes + sq + WALK_CTX_BYTES;
-    }
   }
   if (sparse) {
     const uint32_t tps = 128 / fi.sym_bytes;
@@ -1151,7 +1125,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
 
   ACMPlanInfo &I = p->info;
   I.device = device;
-  I.kernel = p->sieve ? 6 : (p->gram ? 5 : (dense ? 1 : (sparse ? (p->starts ? 4 : 3) : 2)));
+  I.kernel = p->gram ? 5 : (dense ? 1 : (sparse ? (p->starts ? 4 : 3) : 2));
   I.entry_bytes = dense ? entry_bytes : 0;
   I.width = fi.width;
   I.dense_rows = dense ? n : 0;
@@ -1175,8 +1149,16 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
       return ACM_GPU_E_HIP;                                                                        \
     }                                                                                              \
   } while (0)
+  if (const char *e = getenv ("ACM_GPU_GRID_BLOCKS")) {
+    /* tests: fewer workgroups than CUs, so that one wave sees many tiles of a small text (the
+     * overflow path of the item regions fires hundreds of times per wave) */
+    const int g = atoi (e);
+    if (g >= 1 && g < p->cu_count)
+      p->cu_count = g;
+    I.grid_blocks = dense ? (uint32_t)p->cu_count : (uint32_t)p->cu_count * 16;
+  }
   if (p->gram) {
-    I.lds_bytes = p->sieve ? p->sieve_lds_bytes : p->gram_lds_bytes;
+    I.lds_bytes = p->gram_lds_bytes;
     I.block_threads = SPARSE_THREADS;
     I.grid_blocks = (uint32_t)p->cu_count;
     I.streams = 1;
@@ -1195,12 +1177,6 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
         PLAN_TRY (hipFuncSetAttribute (starts_kernel_ptr (fi.sym_bytes, p->starts_lut_lds, co != 0),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->starts_lds_bytes));
     }
-  }
-  if (p->sieve) {
-    PLAN_TRY (hipFuncSetAttribute (reinterpret_cast<const void *> (&scan_sieve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)p->sieve_lds_bytes));
-    PLAN_TRY (hipFuncSetAttribute (reinterpret_cast<const void *> (&scan_sieve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)p->sieve_lds_bytes));
   }
   if (p->gram) {
     for (int co = 0; co < 2; co++)
@@ -1245,7 +1221,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     for (uint32_t i = 0; i < fv.n_keys32; i++)
       p->cls32_known[fv.keys32[i]] = fv.keys32_class[i];
     p->cls32_reps.assign (fv.class_rep32, fv.class_rep32 + fv.n_classes);
-    if (hipMalloc (reinterpret_cast<void **> (&p->d_unknown), (size_t)(ACMPlan::CLS32_UNKNOWN_CAP + 1) * 4) != hipSuccess) {
+    if (hipMalloc (reinterpret_cast<void **> (&p->d_unknown), (size_t)(p->cls32_cap + 1) * 4) != hipSuccess) {
       acm_gpu_plan_destroy (p);
       return ACM_GPU_E_NOMEM;
     }
@@ -1316,8 +1292,9 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
     acm_gpu_plan_destroy (plan->delta);
   plan->delta = nullptr;
   for (auto &ev : plan->events) {
-    (void)hipEventDestroy (ev.first);
-    (void)hipEventDestroy (ev.second);
+    (void)hipEventDestroy (ev.start);
+    (void)hipEventDestroy (ev.scan_done);
+    (void)hipEventDestroy (ev.all_done);
   }
   if (plan->blob)
     (void)hipFree (plan->blob);
@@ -1325,6 +1302,10 @@ acm_gpu_plan_destroy (ACMPlan *plan) {
     (void)hipFree (plan->d_items);
   if (plan->d_fill && !plan->items_owner)
     (void)hipFree (plan->d_fill);
+  if (plan->d_holes)
+    (void)hipFree (plan->d_holes);
+  if (plan->d_spill)
+    (void)hipFree (plan->d_spill);
   if (plan->d_total)
     (void)hipFree (plan->d_total);
   if (plan->mir) {
@@ -1354,6 +1335,8 @@ acm_gpu_plan_info (const ACMPlan *plan, ACMPlanInfo *info) {
   *info = plan->info;
   info->delta_keywords = plan->delta ? plan->delta->finfo.n_keywords : 0;
   info->merges = plan->merges;
+  info->records_direct = ((plan->gram && !plan->gram_wide) || plan->info.kernel == 2) ? 1u : 0u;
+  info->reserved = 0;
 }
 
 extern "C" int
@@ -1378,35 +1361,46 @@ acm_gpu_plan_timing (ACMPlan *plan, int enable) {
   plan->timing = enable != 0;
   plan->events_used = 0;
   plan->timing_ms = 0;
+  plan->timing_all_ms = 0;
   plan->timing_launches = 0;
   return ACM_GPU_OK;
 }
 
 extern "C" int
-acm_gpu_plan_timing_read (ACMPlan *plan, double *total_ms, uint64_t *launches) {
+acm_gpu_plan_timing_read_all (ACMPlan *plan, double *scan_ms, double *all_ms, uint64_t *launches) {
   if (!plan)
     return ACM_GPU_E_ARG;
   HIP_TRY (hipSetDevice (plan->device));
   for (size_t i = 0; i < plan->events_used; i++) {
-    HIP_TRY (hipEventSynchronize (plan->events[i].second));
+    HIP_TRY (hipEventSynchronize (plan->events[i].all_done));
     float ms = 0;
-    HIP_TRY (hipEventElapsedTime (&ms, plan->events[i].first, plan->events[i].second));
+    HIP_TRY (hipEventElapsedTime (&ms, plan->events[i].start, plan->events[i].scan_done));
     plan->timing_ms += ms;
+    HIP_TRY (hipEventElapsedTime (&ms, plan->events[i].start, plan->events[i].all_done));
+    plan->timing_all_ms += ms;
     plan->timing_launches++;
   }
   plan->events_used = 0;
-  if (total_ms)
-    *total_ms = plan->timing_ms;
+  if (scan_ms)
+    *scan_ms = plan->timing_ms;
+  if (all_ms)
+    *all_ms = plan->timing_all_ms;
   if (launches)
     *launches = plan->timing_launches;
   return ACM_GPU_OK;
 }
 
+extern "C" int
+acm_gpu_plan_timing_read (ACMPlan *plan, double *total_ms, uint64_t *launches) {
+  return acm_gpu_plan_timing_read_all (plan, total_ms, nullptr, launches);
+}
+
 namespace {
 
 int
-timing_begin (ACMPlan *p, hipStream_t st, hipEvent_t *stop) {
+timing_begin (ACMPlan *p, hipStream_t st, hipEvent_t *stop, hipEvent_t *stop_all) {
   *stop = nullptr;
+  *stop_all = nullptr;
   if (!p->timing)
     return ACM_GPU_OK;
   if (p->events_used == p->events.size ()) {
@@ -1415,15 +1409,17 @@ timing_begin (ACMPlan *p, hipStream_t st, hipEvent_t *stop) {
       if (rc)
         return rc;
     } else {
-      hipEvent_t a, b;
-      HIP_TRY (hipEventCreate (&a));
-      HIP_TRY (hipEventCreate (&b));
-      p->events.emplace_back (a, b);
+      ACMPlan::LaunchEvents ev;
+      HIP_TRY (hipEventCreate (&ev.start));
+      HIP_TRY (hipEventCreate (&ev.scan_done));
+      HIP_TRY (hipEventCreate (&ev.all_done));
+      p->events.push_back (ev);
     }
   }
   auto &ev = p->events[p->events_used++];
-  HIP_TRY (hipEventRecord (ev.first, st));
-  *stop = ev.second;
+  HIP_TRY (hipEventRecord (ev.start, st));
+  *stop = ev.scan_done;
+  *stop_all = ev.all_done;
   return ACM_GPU_OK;
 }
 
@@ -1462,7 +1458,9 @@ set_tile_pool (ACMPlan *p, Launch &a, uint32_t waves) {
   const uint32_t tiles = a.range_end - a.range_begin;
   const uint32_t pool = tiles >= waves * 8 ? tiles / 16 : 0;
   a.static_end = a.range_end - pool;
-  a.pool_class_tiles = (pool + POOL_CLASSES - 1) / POOL_CLASSES;
+  const uint32_t blocks = waves / (SPARSE_THREADS / WAVE) > 0 ? waves / (SPARSE_THREADS / WAVE) : 1;
+  a.pool_classes = blocks < POOL_CLASSES ? blocks : POOL_CLASSES; /* (grids of fewer blocks than parts: every part must have a block) */
+  a.pool_class_tiles = (pool + a.pool_classes - 1) / a.pool_classes;
   a.pool_ctr = p->d_pool_ctr + (p->launch_seq & 1) * POOL_CLASSES * POOL_CTR_STRIDE;
   a.pool_reset = p->d_pool_ctr + ((p->launch_seq & 1) ^ 1) * POOL_CLASSES * POOL_CTR_STRIDE;
   p->launch_seq++;
@@ -1534,23 +1532,31 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t 
   if ((tiles + wpb - 1) / wpb < grid)
     grid = (tiles + wpb - 1) / wpb;
   set_tile_pool (p, a, grid * wpb);
-  void *items = COUNT_ONLY ? nullptr : p->d_items;
-  uint32_t *fill = COUNT_ONLY ? nullptr : p->d_fill;
-  if (p->sieve) {
-    SieveK V = p->VK;
-    V.G.R = (uint32_t)R;
-    void *vargs[] = { &V, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
-    HIP_TRY (hipLaunchKernel (reinterpret_cast<const void *> (&scan_sieve_kernel<COUNT_ONLY>), dim3 (grid), dim3 (SPARSE_THREADS), vargs,
-                              p->sieve_lds_bytes, st));
-  } else {
-    void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill };
-    HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts, p->gram_wide), dim3 (grid), dim3 (SPARSE_THREADS), args,
-                              p->gram_lds_bytes, st));
-  }
+  /* narrow alphabets: the kernel writes the records itself (no item buffer, no expansion; the holes
+   * its waves leave in their last chunks are closed right behind it); hashed windows: hits parked
+   * per wave and expanded as in the start-parallel kernel */
+  const bool direct = !p->gram_wide;
+  void *items = (COUNT_ONLY || direct) ? nullptr : p->d_items;
+  uint32_t *fill = (COUNT_ONLY || direct) ? nullptr : p->d_fill;
+  void *holes = (!COUNT_ONLY && direct) ? p->d_holes : nullptr;
+  void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill, &holes };
+  HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts, p->gram_wide), dim3 (grid), dim3 (SPARSE_THREADS), args,
+                            p->gram_lds_bytes, st));
   if (stop)
     HIP_TRY (hipEventRecord (stop, st));
-  if (!COUNT_ONLY)
-    launch_expand_hits (p, E, grid * wpb, st);
+  if (!COUNT_ONLY) {
+    if (direct) {
+      const uint32_t n_waves = grid * wpb;
+      uint32_t npow = 64;
+      while (npow < n_waves)
+        npow <<= 1;
+      const uint32_t blocks = n_waves / 16 > 0 ? n_waves / 16 : 1; /* 16 holes per block */
+      hipLaunchKernelGGL (close_holes_kernel, dim3 (blocks), dim3 (CLOSE_THREADS), npow * 16, st, E, static_cast<const RecHole *> (p->d_holes),
+                          n_waves, npow, reinterpret_cast<unsigned int *> (p->d_total + 1));
+      HIP_TRY (hipGetLastError ());
+    } else
+      launch_expand_hits (p, E, grid * wpb, st);
+  }
   return ACM_GPU_OK;
 }
 
@@ -1591,7 +1597,13 @@ ensure_item_buffer (ACMPlan *user, uint64_t n, uint32_t symbols_per_item = 256, 
    * other on one stream, and a fresh 140 MB buffer (with the waits it takes to set one up) for
    * every delta made every dictionary change cost more than the delta itself */
   ACMPlan *p = user->items_owner ? user->items_owner : user;
-  const uint32_t regions = p->info.grid_blocks * (DENSE_THREADS / WAVE);
+  /* one region per wave of the kernels that park items (dense, 4-gram, start-parallel: one block of
+   * 16 waves per CU) -- of the plan that SCANS, not of the buffer's owner: an owner of the CSR kind
+   * (a plan made from an empty machine) has cu_count * 16 single-wave blocks, which sized the
+   * buffer of a dense delta at 65,536 regions x 4,352 items = 2.3 GB */
+  uint32_t regions = (uint32_t)user->cu_count * (DENSE_THREADS / WAVE);
+  if (p->d_items && p->regions > regions)
+    regions = p->regions; /* (shared by a plan and its delta: never shrink what the other one uses) */
   uint64_t per = (n / symbols_per_item + regions - 1) / regions;
   per = (per + 63) / 64 * 64;
   if (per < min_items)
@@ -1624,27 +1636,35 @@ ensure_item_buffer (ACMPlan *user, uint64_t n, uint32_t symbols_per_item = 256, 
   return ACM_GPU_OK;
 }
 
-template <bool CONT, bool COUNT_ONLY, int THREADS, int REGIONS>
-void
-launch_expand (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, const ExpandTail &tail, hipStream_t st) {
-  const dim3 g ((regions_used + REGIONS - 1) / REGIONS);
-  hipLaunchKernelGGL ((expand_items_kernel<CONT, COUNT_ONLY, THREADS, REGIONS>), g, dim3 (THREADS), 0, st, E,
-                      static_cast<const uint2 *> (p->d_items), p->region_items, p->d_fill, tail);
+/* expand_items_once_kernel: 1024 threads per 16 regions (one block per CU on config 2), the items
+ * of 4 rounds in registers, one atomic per block (measured against one atomic per round of 1,024
+ * items, smaller blocks and fewer rounds: DESIGN.md 4.2) */
+/* hole descriptors and spill area of a plan whose scan kernel writes the records itself */
+int
+ensure_direct_buffers (ACMPlan *p) {
+  const uint32_t regions = (uint32_t)p->cu_count * (SPARSE_THREADS / WAVE);
+  if (p->d_holes && p->d_spill && p->direct_regions >= regions)
+    return ACM_GPU_OK;
+  if (p->d_holes || p->d_spill)
+    HIP_TRY (hipDeviceSynchronize ());
+  if (p->d_holes)
+    HIP_TRY (hipFree (p->d_holes));
+  if (p->d_spill)
+    HIP_TRY (hipFree (p->d_spill));
+  p->d_holes = p->d_spill = nullptr;
+  if (hipMalloc (&p->d_holes, (size_t)regions * sizeof (RecHole)) != hipSuccess ||
+      hipMalloc (&p->d_spill, (size_t)regions * REC_CHUNK * 16) != hipSuccess)
+    return ACM_GPU_E_NOMEM;
+  p->direct_regions = regions;
+  return ACM_GPU_OK;
 }
 
 template <bool CONT, bool COUNT_ONLY>
 void
 launch_expand_cfg (ACMPlan *p, const EmitCtx &E, uint32_t regions_used, const ExpandTail &tail, hipStream_t st) {
-  if (p->expand_mode == 2) {
-    const dim3 g ((regions_used + 15) / 16);
-    hipLaunchKernelGGL ((expand_items_once_kernel<CONT, COUNT_ONLY, 1024, 16, 4>), g, dim3 (1024), 0, st, E,
-                        static_cast<const uint2 *> (p->d_items), p->region_items, p->d_fill, tail);
-    return;
-  }
-  /* 1024 threads per 16 regions (one block per CU on config 2) measured best: 41 us against 47
-   * for 8 regions and 62 for 32 (fewer, larger blocks: too few items in flight; more, smaller
-   * blocks: the single record counter's atomic rate becomes the limit) */
-  launch_expand<CONT, COUNT_ONLY, 1024, 16> (p, E, regions_used, tail, st);
+  const dim3 g ((regions_used + 15) / 16);
+  hipLaunchKernelGGL ((expand_items_once_kernel<CONT, COUNT_ONLY, 1024, 16, 4>), g, dim3 (1024), 0, st, E,
+                      static_cast<const uint2 *> (p->d_items), p->region_items, p->d_fill, tail);
 }
 
 /* scan kernel, then the expansion of what it parked; the caller's counter is written by the
@@ -1663,7 +1683,8 @@ launch_dense (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
   /* the last 1/16 of the tiles is the dynamic pool (none for inputs of a few tiles per wave) */
   const uint32_t pool = a.range_end >= grid * wpb * 8 ? a.range_end / 16 : 0;
   a.static_end = a.range_end - pool;
-  a.pool_class_tiles = (pool + POOL_CLASSES - 1) / POOL_CLASSES;
+  a.pool_classes = grid < POOL_CLASSES ? grid : POOL_CLASSES;
+  a.pool_class_tiles = (pool + a.pool_classes - 1) / a.pool_classes;
   a.pool_ctr = p->d_pool_ctr + (p->launch_seq & 1) * POOL_CLASSES * POOL_CTR_STRIDE;
   a.pool_reset = p->d_pool_ctr + ((p->launch_seq & 1) ^ 1) * POOL_CLASSES * POOL_CTR_STRIDE;
   p->launch_seq++;
@@ -1969,7 +1990,7 @@ classify_symbol32 (const ACMPlan *p, uint32_t sym) {
 int
 upload_cls32_table (ACMPlan *p, hipStream_t st) {
   uint32_t slots = p->cls32_slots ? p->cls32_slots : 1u << 12;
-  while ((uint64_t)slots < 4ull * (p->cls32_known.size () + ACMPlan::CLS32_UNKNOWN_CAP))
+  while ((uint64_t)slots < 4ull * (p->cls32_known.size () + p->cls32_cap))
     slots <<= 1;
   if (slots != p->cls32_slots) {
     if (p->d_cls32) {
@@ -2018,11 +2039,13 @@ classify_text32 (ACMPlan *p, const void *d_text, uint64_t n, hipStream_t st) {
   const uint64_t want_blocks = (n + 255) / 256;
   const uint32_t grid = (uint32_t)(want_blocks < (uint64_t)p->cu_count * 32 ? want_blocks : (uint64_t)p->cu_count * 32);
   std::vector<uint32_t> fresh;
-  for (int round = 0; round < 1 << 20; round++) {
+  /* every pass but the last classifies a full list: at most KNOWN_MAX / CAP_MIN passes with a list
+   * that never grows, far fewer with one that doubles */
+  for (uint32_t round = 0; round < ACMPlan::CLS32_KNOWN_MAX / ACMPlan::CLS32_CAP_MIN + 64; round++) {
     HIP_TRY (hipMemsetAsync (p->d_unknown, 0, 4, st));
     hipLaunchKernelGGL (classify32_kernel, dim3 (grid), dim3 (256), 0, st, static_cast<const uint32_t *> (d_text),
                         static_cast<uint32_t *> (p->d_remap), n, p->d_cls32, p->cls32_slots - 1, p->d_unknown + 1, p->d_unknown,
-                        ACMPlan::CLS32_UNKNOWN_CAP);
+                        p->cls32_cap);
     HIP_TRY (hipGetLastError ());
     uint32_t cnt = 0;
     HIP_TRY (hipMemcpyWithStream (&cnt, p->d_unknown, 4, hipMemcpyDeviceToHost, st));
@@ -2030,12 +2053,25 @@ classify_text32 (ACMPlan *p, const void *d_text, uint64_t n, hipStream_t st) {
       return ACM_GPU_OK;
     if (!p->cmp32)
       return ACM_GPU_E_INELIGIBLE; /* tables without their machine: nothing to classify new symbols with */
-    const uint32_t listed = cnt < ACMPlan::CLS32_UNKNOWN_CAP ? cnt : ACMPlan::CLS32_UNKNOWN_CAP;
+    const uint32_t listed = cnt < p->cls32_cap ? cnt : p->cls32_cap;
+    if (p->cls32_known.size () + listed > ACMPlan::CLS32_KNOWN_MAX) {
+      fprintf (stderr, "acm_gpu: the text brings more than %u distinct symbols to a comparator-class plan\n", ACMPlan::CLS32_KNOWN_MAX);
+      return ACM_GPU_E_INELIGIBLE;
+    }
     fresh.resize (listed);
     HIP_TRY (hipMemcpyWithStream (fresh.data (), p->d_unknown + 1, (size_t)listed * 4, hipMemcpyDeviceToHost, st));
     for (uint32_t sym : fresh)
       if (!p->cls32_known.count (sym))
         p->cls32_known[sym] = classify_symbol32 (p, sym);
+    if (cnt >= p->cls32_cap && p->cls32_cap < ACMPlan::CLS32_CAP_MAX) {
+      /* the list was full: the text has more to bring -- a longer list for the next pass */
+      HIP_TRY (hipStreamSynchronize (st));
+      HIP_TRY (hipFree (p->d_unknown));
+      p->d_unknown = nullptr;
+      p->cls32_cap *= 2;
+      if (hipMalloc (reinterpret_cast<void **> (&p->d_unknown), (size_t)(p->cls32_cap + 1) * 4) != hipSuccess)
+        return ACM_GPU_E_NOMEM;
+    }
     rc = upload_cls32_table (p, st); /* also clears the slots claimed for symbols that did not fit the list */
     if (rc)
       return rc;
@@ -2097,12 +2133,17 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     HIP_TRY (hipMemcpyAsync (p->d_remap, d_text, (size_t)n * sb, hipMemcpyDeviceToDevice, st));
     d_text = p->d_remap;
   }
-  if (use_dense || (!COUNT_ONLY && (p->gram || p->starts))) {
-    /* 4-gram plans see dense matches (config 3: one per 38 symbols): room for one hit per 16,
-     * per 8 when the dictionary has keywords of 1-3 symbols (12k keywords of 3-11 letters on
-     * random a-z text: one match per 13); past that a wave reserves records 64 at a time */
-    int rc = ensure_item_buffer (p, n < p->segment ? n : p->segment, p->gram && !p->sieve ? (p->gram_shorts ? 8 : 16) : 256,
+  const bool direct = p->gram && !p->gram_wide; /* records straight from the scan kernel: no item buffer */
+  if (use_dense || (!COUNT_ONLY && !direct && (p->gram || p->starts))) {
+    /* 4-gram plans over hashed windows see dense matches: room for one hit per 16 symbols, per 8
+     * when the dictionary has keywords of 1-3 symbols; past that a wave reserves records 64 at a time */
+    int rc = ensure_item_buffer (p, n < p->segment ? n : p->segment, p->gram ? (p->gram_shorts ? 8 : 16) : 256,
                                  use_dense ? DENSE_MIN_REGION_ITEMS : 256);
+    if (rc)
+      return rc;
+  }
+  if (!COUNT_ONLY && direct) {
+    int rc = ensure_direct_buffers (p);
     if (rc)
       return rc;
   }
@@ -2121,6 +2162,8 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   E.kw4 = p->d_kw4;
   E.chain = p->d_chain;
   E.chain_base = p->K.HD;
+  E.spill = static_cast<uint4 *> (p->d_spill);
+  E.spill_slots = (!COUNT_ONLY && direct) ? (uint64_t)p->direct_regions * REC_CHUNK : 0;
   E.error = p->d_total ? reinterpret_cast<unsigned int *> (p->d_total) + 3 : nullptr;
 
   /* segments of at most SEGMENT symbols; each restarts from the root `halo` symbols early
@@ -2140,8 +2183,8 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     E.text = a.text;
     E.n = a.n;
     E.emit_from = a.emit_from;
-    hipEvent_t stop;
-    int rc = timing_begin (p, st, &stop);
+    hipEvent_t stop, stop_all;
+    int rc = timing_begin (p, st, &stop, &stop_all);
     if (rc)
       return rc;
     if (use_dense)
@@ -2162,6 +2205,8 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
           HIP_TRY (hipEventRecord (stop, st));
       }
     }
+    if (!rc && stop_all) /* behind the expansion / hole closing the launch functions enqueue after their scan kernel */
+      HIP_TRY (hipEventRecord (stop_all, st));
     if (rc) {
       /* earlier segments may have left a partial running total and expand ticket behind */
       if (use_dense && p->d_total)
@@ -2493,6 +2538,287 @@ acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint64_t
   cleanup ();
   return ACM_GPU_OK;
 #undef HOST_TRY
+}
+
+/* ------------------------------------------------------------------ several GPUs, one process (include/acm_gpu.h)
+ * contiguous shards, an lmax - 1 halo, tables replicated, no collective on the data
+ * path; the one exchange step is the gather of the ordered records on devices[0] by direct peer
+ * copies (reference model: one shared machine, one cursor per worker, README.md:364). */
+struct ACMMulti {
+  std::vector<int> dev;        /* per shard */
+  std::vector<int> distinct;   /* the devices in use, devices[0] first */
+  std::vector<ACMPlan *> plan; /* per distinct device */
+  std::vector<hipStream_t> stream;
+  uint32_t lmax = 0, sym_bytes = 1;
+  int slot_of (int device) const {
+    for (size_t i = 0; i < distinct.size (); i++)
+      if (distinct[i] == device)
+        return (int)i;
+    return -1;
+  }
+};
+
+extern "C" void
+acm_gpu_multi_destroy (ACMMulti *mu) {
+  if (!mu)
+    return;
+  for (size_t i = 0; i < mu->distinct.size (); i++) {
+    (void)hipSetDevice (mu->distinct[i]);
+    if (i < mu->stream.size () && mu->stream[i]) {
+      (void)hipStreamSynchronize (mu->stream[i]);
+      (void)hipStreamDestroy (mu->stream[i]);
+    }
+    if (i < mu->plan.size () && mu->plan[i])
+      acm_gpu_plan_destroy (mu->plan[i]);
+  }
+  delete mu;
+}
+
+extern "C" int
+acm_gpu_multi_create (ACMachine *machine, const int *devices, int n_shards, ACMMulti **out) {
+  if (!machine || !devices || n_shards < 1 || !out)
+    return ACM_GPU_E_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0)
+    return ACM_GPU_E_NODEVICE;
+  ACMMulti *mu = new (std::nothrow) ACMMulti ();
+  if (!mu)
+    return ACM_GPU_E_NOMEM;
+  for (int r = 0; r < n_shards; r++) {
+    if (devices[r] < 0 || devices[r] >= ndev) {
+      delete mu;
+      return ACM_GPU_E_ARG;
+    }
+    mu->dev.push_back (devices[r]);
+    if (mu->slot_of (devices[r]) < 0)
+      mu->distinct.push_back (devices[r]);
+  }
+  /* one snapshot of the dictionary for every device: the same tables everywhere */
+  ACMFlat *flat = nullptr;
+  int rc = acm_flatten (machine, &flat);
+  if (rc) {
+    delete mu;
+    return rc;
+  }
+  ACMFlatInfo fi;
+  acm_flat_info (flat, &fi);
+  mu->lmax = fi.lmax;
+  mu->sym_bytes = fi.sym_bytes;
+  mu->plan.assign (mu->distinct.size (), nullptr);
+  mu->stream.assign (mu->distinct.size (), nullptr);
+  for (size_t i = 0; i < mu->distinct.size () && !rc; i++) {
+    rc = acm_gpu_plan_create_flat (flat, mu->distinct[i], &mu->plan[i]);
+    if (!rc && (hipSetDevice (mu->distinct[i]) != hipSuccess || hipStreamCreateWithFlags (&mu->stream[i], hipStreamNonBlocking) != hipSuccess))
+      rc = ACM_GPU_E_HIP;
+    /* direct peer copies into devices[0] where the hardware offers them (otherwise the runtime stages the copy) */
+    if (!rc && i > 0) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer (&can, mu->distinct[i], mu->distinct[0]) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess (mu->distinct[0], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+          (void)hipGetLastError ();
+      }
+    }
+  }
+  acm_flat_release (flat);
+  if (rc) {
+    acm_gpu_multi_destroy (mu);
+    return rc;
+  }
+  *out = mu;
+  return ACM_GPU_OK;
+}
+
+extern "C" int
+acm_gpu_multi_shard_bounds (const ACMMulti *mu, uint64_t n, int shard, uint64_t *read_begin, uint64_t *own_begin, uint64_t *own_end) {
+  if (!mu || shard < 0 || shard >= (int)mu->dev.size ())
+    return ACM_GPU_E_ARG;
+  const uint64_t R = mu->dev.size ();
+  /* the rule of sharded.shard_bounds (rank r owns [r N / R, (r + 1) N / R)), with the halo grown to
+   * the next 16-byte boundary of the text so that a shard's buffer can keep the text's alignment */
+  const uint64_t b = n / R * (uint64_t)shard + n % R * (uint64_t)shard / R, e = n / R * (uint64_t)(shard + 1) + n % R * (uint64_t)(shard + 1) / R;
+  const uint64_t per16 = 16 / mu->sym_bytes ? 16 / mu->sym_bytes : 1;
+  const uint64_t warm = mu->lmax > 1 ? mu->lmax - 1 : 0;
+  uint64_t rb = b > warm ? b - warm : 0;
+  rb = rb / per16 * per16;
+  if (read_begin)
+    *read_begin = rb;
+  if (own_begin)
+    *own_begin = b;
+  if (own_end)
+    *own_end = e;
+  return ACM_GPU_OK;
+}
+
+namespace {
+/* shards scanned, ordered and gathered: d_text[r] on dev[r] holds [read_begin_r, own_end_r) */
+int
+multi_scan (ACMMulti *mu, const void *const *d_text, uint64_t n, ACMRecord *d_out, uint64_t capacity, uint64_t *n_found) {
+  const size_t R = mu->dev.size ();
+  struct Shard {
+    ACMRecord *rec = nullptr;
+    uint64_t *cnt = nullptr;
+    void *tmp = nullptr;
+    uint64_t cap = 0, found = 0, rb = 0, b = 0, e = 0;
+    int slot = 0;
+    hipEvent_t done = nullptr;
+  };
+  std::vector<Shard> sh (R);
+  int rc = ACM_GPU_OK;
+  auto cleanup = [&] () {
+    for (auto &s : sh) {
+      (void)hipSetDevice (mu->distinct[s.slot]);
+      (void)hipStreamSynchronize (mu->stream[s.slot]);
+      if (s.rec) (void)hipFree (s.rec);
+      if (s.cnt) (void)hipFree (s.cnt);
+      if (s.tmp) (void)hipFree (s.tmp);
+      if (s.done) (void)hipEventDestroy (s.done);
+    }
+  };
+#define MULTI_TRY(expr)                                                                            \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      fprintf (stderr, "acm_gpu: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString (_e), __FILE__, __LINE__); \
+      cleanup ();                                                                                  \
+      return _e == hipErrorOutOfMemory ? ACM_GPU_E_NOMEM : ACM_GPU_E_HIP;                          \
+    }                                                                                              \
+  } while (0)
+  /* first pass: every shard with a record buffer sized by a guess (one match per 32 symbols); the
+   * count tells which shards need a second pass with the exact size */
+  for (size_t r = 0; r < R; r++) {
+    Shard &s = sh[r];
+    s.slot = mu->slot_of (mu->dev[r]);
+    (void)acm_gpu_multi_shard_bounds (mu, n, (int)r, &s.rb, &s.b, &s.e);
+    MULTI_TRY (hipSetDevice (mu->dev[r]));
+    MULTI_TRY (hipEventCreateWithFlags (&s.done, hipEventDisableTiming));
+    MULTI_TRY (hipMalloc (reinterpret_cast<void **> (&s.cnt), 8));
+    s.cap = (s.e - s.b) / 32 + 4096;
+    MULTI_TRY (hipMalloc (reinterpret_cast<void **> (&s.rec), s.cap * sizeof (ACMRecord)));
+  }
+  for (int pass = 0; pass < 2; pass++) {
+    bool any = false;
+    for (size_t r = 0; r < R; r++) {
+      Shard &s = sh[r];
+      if (pass == 1 && s.found <= s.cap)
+        continue; /* the first pass had room for everything it found */
+      any = true;
+      MULTI_TRY (hipSetDevice (mu->dev[r]));
+      if (pass == 1) {
+        MULTI_TRY (hipFree (s.rec));
+        s.rec = nullptr;
+        s.cap = s.found;
+        MULTI_TRY (hipMalloc (reinterpret_cast<void **> (&s.rec), s.cap * sizeof (ACMRecord)));
+      }
+      /* (shards of one device share its stream: their scans run one after the other) */
+      if (s.e > s.b) {
+        rc = scan_plan<false> (mu->plan[s.slot], d_text[r], s.e - s.rb, s.b - s.rb, s.rb, s.rec, s.cap, s.cnt, mu->stream[s.slot]);
+        if (rc) {
+          cleanup ();
+          return rc;
+        }
+      } else
+        MULTI_TRY (hipMemsetAsync (s.cnt, 0, 8, mu->stream[s.slot]));
+      MULTI_TRY (hipMemcpyAsync (&s.found, s.cnt, 8, hipMemcpyDeviceToHost, mu->stream[s.slot]));
+    }
+    if (!any)
+      break;
+    for (size_t i = 0; i < mu->distinct.size (); i++) {
+      MULTI_TRY (hipSetDevice (mu->distinct[i]));
+      MULTI_TRY (hipStreamSynchronize (mu->stream[i]));
+    }
+  }
+  uint64_t total = 0;
+  for (auto &s : sh)
+    total += s.found;
+  *n_found = total;
+  if (total > capacity) {
+    cleanup ();
+    return ACM_GPU_E_OVERFLOW;
+  }
+  /* canonical order where the records are, then each shard's run into its place on devices[0] */
+  uint64_t off = 0;
+  for (size_t r = 0; r < R; r++) {
+    Shard &s = sh[r];
+    MULTI_TRY (hipSetDevice (mu->dev[r]));
+    hipStream_t st = mu->stream[s.slot];
+    if (s.found > 1) {
+      const size_t tb = acm_gpu_sort_tmp_bytes (s.found);
+      MULTI_TRY (hipMalloc (&s.tmp, tb));
+      rc = acm_gpu_sort_records_device (mu->plan[s.slot], s.rec, s.found, s.tmp, tb, st);
+      if (rc) {
+        cleanup ();
+        return rc;
+      }
+    }
+    if (s.found) {
+      if (mu->dev[r] == mu->dev[0])
+        MULTI_TRY (hipMemcpyAsync (d_out + off, s.rec, s.found * sizeof (ACMRecord), hipMemcpyDeviceToDevice, st));
+      else
+        MULTI_TRY (hipMemcpyPeerAsync (d_out + off, mu->dev[0], s.rec, mu->dev[r], s.found * sizeof (ACMRecord), st));
+    }
+    off += s.found;
+  }
+  for (size_t i = 0; i < mu->distinct.size (); i++) {
+    MULTI_TRY (hipSetDevice (mu->distinct[i]));
+    MULTI_TRY (hipStreamSynchronize (mu->stream[i]));
+  }
+  for (size_t i = 0; i < mu->distinct.size () && !rc; i++)
+    rc = acm_gpu_plan_status (mu->plan[i]);
+  cleanup ();
+  return rc;
+#undef MULTI_TRY
+}
+} // namespace
+
+extern "C" int
+acm_gpu_multi_scan_device (ACMMulti *mu, const void *const *d_shard_text, uint64_t n, ACMRecord *d_records, uint64_t capacity,
+                           uint64_t *n_found) {
+  if (!mu || !n_found || (n && !d_shard_text) || (capacity && !d_records))
+    return ACM_GPU_E_ARG;
+  return multi_scan (mu, d_shard_text, n, d_records, capacity, n_found);
+}
+
+extern "C" int
+acm_gpu_multi_scan_host (ACMMulti *mu, const void *text, uint64_t n, ACMRecord *records, uint64_t capacity, uint64_t *n_found) {
+  if (!mu || !n_found || (n && !text) || (capacity && !records))
+    return ACM_GPU_E_ARG;
+  const size_t R = mu->dev.size ();
+  std::vector<void *> d_text (R, nullptr);
+  ACMRecord *d_out = nullptr;
+  int rc = ACM_GPU_OK;
+  auto cleanup = [&] () {
+    for (size_t r = 0; r < R; r++)
+      if (d_text[r]) {
+        (void)hipSetDevice (mu->dev[r]);
+        (void)hipFree (d_text[r]);
+      }
+    if (d_out) {
+      (void)hipSetDevice (mu->dev[0]);
+      (void)hipFree (d_out);
+    }
+  };
+  for (size_t r = 0; r < R && !rc; r++) {
+    uint64_t rb, b, e;
+    (void)acm_gpu_multi_shard_bounds (mu, n, (int)r, &rb, &b, &e);
+    const size_t bytes = (size_t)(e - rb) * mu->sym_bytes;
+    const int slot = mu->slot_of (mu->dev[r]);
+    if (hipSetDevice (mu->dev[r]) != hipSuccess || hipMalloc (&d_text[r], bytes + 16) != hipSuccess)
+      rc = ACM_GPU_E_NOMEM;
+    else if (bytes && hipMemcpyAsync (d_text[r], static_cast<const unsigned char *> (text) + (size_t)rb * mu->sym_bytes, bytes, hipMemcpyHostToDevice,
+                                      mu->stream[slot]) != hipSuccess)
+      rc = ACM_GPU_E_HIP;
+  }
+  if (!rc && (hipSetDevice (mu->dev[0]) != hipSuccess || hipMalloc (reinterpret_cast<void **> (&d_out), (capacity ? capacity : 1) * sizeof (ACMRecord)) != hipSuccess))
+    rc = ACM_GPU_E_NOMEM;
+  if (!rc)
+    rc = multi_scan (mu, d_text.data (), n, d_out, capacity, n_found);
+  if (!rc && *n_found) {
+    if (hipSetDevice (mu->dev[0]) != hipSuccess || hipMemcpy (records, d_out, *n_found * sizeof (ACMRecord), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = ACM_GPU_E_HIP;
+  }
+  cleanup ();
+  return rc;
 }
 
 /* the reference's dictionaries grow while they are used (README.md:352-356,

@@ -208,7 +208,7 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
    * atomics per counter far below what one address sustains).  Blocks ran up to 6% apart. */
   const uint32_t static_tiles = A.static_end - A.range_begin;
   const uint32_t blk_tiles = blockIdx.x < static_tiles ? (static_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-  const uint32_t cls = blockIdx.x * POOL_CLASSES / gridDim.x;
+  const uint32_t cls = blockIdx.x * A.pool_classes / gridDim.x;
   const uint32_t cls_begin = A.static_end + cls * A.pool_class_tiles;
   const uint32_t cls_tiles = cls_begin >= A.range_end ? 0
                              : (A.range_end - cls_begin < A.pool_class_tiles ? A.range_end - cls_begin : A.pool_class_tiles);

@@ -260,7 +260,19 @@ template <bool CONT, bool COUNT_ONLY, int S>
 __device__ __forceinline__ void
 region_make_room (const EmitCtx &E, Spill *sp) {
   if (sp->capacity - sp->fill < 16u * S * WAVE + QCAP) {
+    /* flush_queue reads back, lane by lane, items that OTHER lanes of this wave parked with plain
+     * stores (queue_drain), possibly at addresses an earlier flush has read before (the region
+     * starts over below).  One wave's vector memory operations reach the CU's L1 in program order
+     * and the L1 is shared by the whole CU, so the loads see the stores -- but nothing in the
+     * program said so: the ordering is spelled out here (release at workgroup scope + the wave's
+     * own stores drained) rather than left to that.  The path runs once per ~2,000 items of a
+     * wave; tests/test_gpu_parity.py::test_dense_region_overflow_many_times_per_wave drives it
+     * hundreds of times per wave on a one-block grid (ACM_GPU_GRID_BLOCKS=1). */
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
     flush_queue<CONT, COUNT_ONLY> (E, sp->region, sp->fill);
+    /* ... and the region is written again from its start only after those loads have returned */
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
     sp->fill = 0;
   }
 }

@@ -66,7 +66,7 @@ struct GramK {
    * three record gathers went to memory for a 128-byte line each, 5.5 x the algorithmic bytes. */
   const uint32_t *g4prefix;
   const uint32_t *g4entry; /* by rank, 3 words: {children mask | terminal << 31, state id of the first child, keyword id} */
-  uint32_t kw_inline;     /* keyword ids fit a hit's word beside HIT_KW (always, short of 2^28 keywords) */
+  uint32_t kw_inline;     /* wide alphabets: keyword ids fit a hit's word beside HIT_KW (always, short of 2^28 keywords) */
   /* the walks start one level down, at the depth-5 state the 5th symbol leads to (children are
    * numbered consecutively in symbol order: first child + set mask bits below the class), and ask
    * g5peek[that state - d5_begin] = {its record, the symbol of its only edge | GRAM_NO_PEEK}
@@ -115,7 +115,7 @@ constexpr uint32_t WT_TERM = 0x80000000u, WT_KIDS = 0x40000000u;
 template <bool COUNT_ONLY, bool SHORTS, bool WIDE>
 __global__ __launch_bounds__ (SPARSE_THREADS) void
 scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
-                  uint32_t *fill) {
+                  uint32_t *fill, RecHole *holes) {
   extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
   constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
   constexpr uint32_t GROUP = WAVE * 16;
@@ -130,11 +130,12 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   /* LDS queues per wave, 8-byte items: first queue (QCAP: up to 63 waiting + 64 from one position),
    * walk queue (GRAM_Q2: up to 63 waiting + what one batch sends on, with room made first when
    * that is more than 33), short-keyword queue (QCAP, SHORTS only), hit buffer (wide alphabets) */
-  constexpr bool DIRECT = !WIDE; /* narrow alphabets: hits go straight to the wave's region, no LDS hit buffer */
+  constexpr bool DIRECT = !WIDE; /* narrow alphabets: 16-byte records straight into the caller's buffer (dev_starts.h: WaveRec), no hits */
   constexpr uint32_t HB = DIRECT ? 0u : HITS_STRIDE;
   uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * ((NQ - 1) * QCAP + GRAM_Q2 + HB) * 8);
   StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4); /* see scan_starts_kernel */
   EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
+  WaveRec *Ws = reinterpret_cast<WaveRec *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K + WALK_CTX_E); /* one per wave */
   if (threadIdx.x == 0) {
     *next_tile = 0;
     StartsK Kc{};
@@ -144,7 +145,6 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     Kc.remap_base = WIDE ? K.d4_begin : K.d5_begin;
     Kc.peek = K.g5peek;
     Kc.peek_packed = K.peek_packed;
-    Kc.region_items = region_items;
     *Ks = Kc;
     *Es = E;
   }
@@ -156,10 +156,14 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   uint2 *q2 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * GRAM_Q2;
   uint2 *q3 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * (QCAP + GRAM_Q2) + wib * QCAP; /* SHORTS only */
   const uint32_t wave_id = blockIdx.x * WAVES + wib;
-  uint2 *hits = DIRECT ? (COUNT_ONLY ? nullptr : items + (size_t)wave_id * region_items)
+  uint2 *hits = DIRECT ? reinterpret_cast<uint2 *> (Ws + wib)
                        : reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * ((NQ - 1) * QCAP + GRAM_Q2) + wib * HITS_STRIDE + 2;
   if (!DIRECT)
     hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
+  else if (lane == 0) {
+    WaveRec w0{};
+    Ws[wib] = w0; /* no chunk yet: limit 0 sends the first batch through emit_records_slow */
+  }
   const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
   /* block b takes the tiles b, b + gridDim.x, ... (match density is rarely even along a text:
    * contiguous shares left two blocks of config 3 working 1 ms after all others had finished),
@@ -168,6 +172,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   const uint32_t last_blk = (A.n - 1) / 16;
   uint32_t qn1 = 0, qn2 = 0, qn3 = 0;
   unsigned long long counted = 0;
+  RecState rs = { 0ull, 0u }; /* DIRECT: the wave's chunk of records (no chunk yet) */
   /* batches of the first queue whose records are in flight: a pipeline of GRAM_DEPTH batches
    * (the gather of a batch has the time it takes the scan to fill that many more before it is
    * looked at: one batch ahead left the L2 / MALL latency exposed).  Narrow alphabets: the record
@@ -200,6 +205,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, WIDE ? 1 : 2> (Ks, Es, text, q2, qn2, n_items, hits, counted);
     qn2 = uniform ((uint32_t)(r >> 32));
     counted = (uint32_t)r;
+    if (DIRECT && !COUNT_ONLY)
+      rs = rec_state_load (hits); /* (the walk may have gone on to the next chunk) */
     DIAG (d_walk += __builtin_readcyclecounter () - d_c0; d_calls++; d_items += n_items;)
   };
   /* Second sieve on the oldest pending batch, in three parts so that a pipeline step can put the
@@ -229,14 +236,14 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
        * expand_hits_kernel spent 0.2 of its 0.52 ms per 2 GiB of config 3 on the gather by rank) */
       st_term = term;
       st_pos = pend_item[0].x + 3;
-      st_what = (!WIDE && K.kw_inline) ? pend_rw[0] | HIT_KW : (pend_ry[0] - K.d4_begin) | HIT_LEN4;
+      st_what = DIRECT ? pend_rw[0] : (pend_ry[0] - K.d4_begin) | HIT_LEN4; /* narrow: the keyword's id itself (the entry brought it) */
     } else
       st_term = false;
   };
   /* (reported apart from the test: a pipeline step of the narrow kernel puts the store behind
    * its gathers, so that the step's own wait for the older gathers does not wait for it) */
   auto emit_stashed = [&] () {
-    emit_terminals<COUNT_ONLY, DIRECT> (E, st_term, st_pos, st_what, lane, hits, counted, Es, region_items);
+    emit_terminals<COUNT_ONLY, DIRECT> (E, st_term, st_pos, st_what, 4u, lane, hits, counted, Es, DIRECT ? &rs : nullptr);
     if (!COUNT_ONLY)
       counted = uniform ((uint32_t)counted);
     st_term = false;
@@ -362,7 +369,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
         e = K.stab[slot];
       }
       const uint32_t end = it.x + (it.y >> 24) - 1;
-      emit_terminals<COUNT_ONLY, DIRECT> (E, valid && e.y != 0 && end >= E.emit_from, end, e.y, lane, hits, counted, Es, region_items);
+      emit_terminals<COUNT_ONLY, DIRECT> (E, valid && e.y != 0 && end >= E.emit_from, end, e.y, 0u, lane, hits, counted, Es, DIRECT ? &rs : nullptr);
       if (!COUNT_ONLY)
         counted = uniform ((uint32_t)counted);
       return;
@@ -374,7 +381,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
 #pragma unroll
     for (uint32_t d = 0; d < 3; d++) {
       const bool hit = ((nib >> d) & 1u) && it.x + d >= E.emit_from;
-      emit_terminals<COUNT_ONLY, DIRECT> (E, hit, it.x + d, d == 0 ? rec.x : (d == 1 ? rec.y : rec.z), lane, hits, counted, Es, region_items);
+      emit_terminals<COUNT_ONLY, DIRECT> (E, hit, it.x + d, d == 0 ? rec.x : (d == 1 ? rec.y : rec.z), d + 1, lane, hits, counted, Es, DIRECT ? &rs : nullptr);
       if (!COUNT_ONLY)
         counted = uniform ((uint32_t)counted);
     }
@@ -558,8 +565,13 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       atomicAdd (E.count, (unsigned long long)total);
   } else {
     if (DIRECT) {
-      if (lane == 0 && fill)
-        fill[wave_id] = (uint32_t)counted;
+      /* what is left of the wave's last chunk is a hole for close_holes_kernel */
+      if (lane == 0 && holes) {
+        const WaveRec w = Ws[wib];
+        const unsigned long long at = (((unsigned long long)w.base_hi << 32) | w.base_lo) + (uint32_t)counted;
+        RecHole h = { (uint32_t)at, (uint32_t)(at >> 32), w.have ? REC_CHUNK - (uint32_t)counted : 0u, 0u };
+        holes[wave_id] = h;
+      }
     } else {
       if (counted)
         flush_hits (E, hits, (uint32_t)counted, lane);

@@ -80,6 +80,11 @@ classify32_kernel (const uint32_t *__restrict__ in, uint32_t *__restrict__ out, 
     for (uint32_t probes = 0; probes <= mask; probes++) {
       unsigned long long slot = table[h]; /* {symbol, class + 1}; 0 = empty */
       if ((uint32_t)(slot >> 32) == 0) {
+        /* the list is full: claim nothing more (the table has room for the symbols the host knows
+         * plus one list's worth: claims beyond that would fill it and turn every later miss into a
+         * walk over all of it).  The pass is repeated anyway once the host has classified the list. */
+        if (__hip_atomic_load (unknown_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= unknown_cap)
+          break;
         const unsigned long long mine = ((unsigned long long)CLS32_PENDING << 32) | k;
         const unsigned long long old = atomicCAS (&table[h], 0ull, mine);
         if (old == 0) {

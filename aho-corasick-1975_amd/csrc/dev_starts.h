@@ -40,7 +40,6 @@ struct StartsK {
    * depth-5 state; peek[id - remap_base] = {its record, the symbol of its only edge or
    * GRAM_NO_PEEK} */
   const uint32_t *peek;
-  uint32_t region_items; /* walk_starts<.., 2>: hits go straight to the wave's region of this many items */
   uint32_t peek_packed; /* 4 bytes per state: record | symbol << 23 | "look at the record" << 31; else {record, symbol or GRAM_NO_PEEK} */
 };
 constexpr uint32_t ST_ALWAYS = 0x80000000u, ST_SECOND = 0x40000000u, ST_STATE = 0x3FFFFFFFu;
@@ -182,31 +181,247 @@ expand_hits_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint32
   }
 }
 
-/* the wave's region is full and there is no LDS buffer in between (DIRECT): this batch's hits as
- * records straight from the registers, one atomic for all of them (rare, out of line) */
-__device__ __noinline__ void
-emit_overflow (const EmitCtx *Ep, bool hit, uint32_t p, uint32_t st) {
-  const EmitCtx &E = *Ep;
-  const uint64_t m = __ballot (hit);
-  const uint32_t total = (uint32_t)__popcll (m);
-  unsigned long long slot = 0;
-  if (lane_id () == 0)
-    slot = atomicAdd (E.count, (unsigned long long)total);
-  slot = ((unsigned long long)__shfl ((uint32_t)(slot >> 32), 0, WAVE) << 32) | __shfl ((uint32_t)slot, 0, WAVE);
-  slot += rank_below (m);
-  if (hit && slot < E.capacity)
-    write_hit_record (E, make_uint2 (p, st), slot);
+/* ---- records straight from the 4-gram kernel (narrow alphabets; DIRECT below)
+ * Round 2 parked 8-byte hits in a region per wave and had expand_hits_kernel turn them into
+ * 16-byte records afterwards: 0.30 ms beside 2.1 ms of scanning per 2 GiB of config 3, 8 B written
+ * + 8 B read back per record.  Now a wave writes the records themselves, into chunks of
+ * REC_CHUNK slots of the caller's buffer that it reserves with one atomicAdd on the record counter
+ * (13 per wave and launch on config 3; a single address takes ~90 per microsecond).  What a wave
+ * leaves unused of its last chunk is a hole: it reports {first slot, length} in RecHole and
+ * close_holes_kernel moves the records that lie beyond the dense count into the holes and rewinds
+ * the counter (at most one chunk per wave).  The caller's buffer may be exactly as long as the
+ * number of matches: slots past its capacity are kept in the plan's spill area (one chunk per
+ * wave), which the closing pass reads from -- so nothing is dropped because of holes.
+ * Per wave in LDS (WaveRec): where slot 0 of the current chunk is (in the caller's buffer or in the
+ * spill area), the chunk's first slot, and how many slots the fast path may use. */
+constexpr uint32_t REC_CHUNK = 1024;
+struct WaveRec {
+  uint32_t dst_lo, dst_hi;   /* address of slot 0 of the current chunk (meaningless while limit == 0) */
+  uint32_t base_lo, base_hi; /* index of that slot */
+  uint32_t limit;            /* REC_CHUNK for a chunk that lies entirely on one side of the capacity, else 0: slow path only */
+  uint32_t have;             /* a chunk has been reserved */
+  uint32_t pad[2];
+};
+struct RecHole {
+  uint32_t start_lo, start_hi, len, pad;
+};
+
+/* where record `slot` goes: the caller's buffer below the capacity, the spill area for the next
+ * spill_slots, nowhere beyond (a true overflow: the count alone tells) */
+__device__ __forceinline__ uint4 *
+record_address (const EmitCtx &E, unsigned long long slot) {
+  if (slot < E.capacity)
+    return reinterpret_cast<uint4 *> (&E.records[slot]);
+  if (slot - E.capacity < E.spill_slots)
+    return E.spill + (slot - E.capacity);
+  return nullptr;
 }
 
-/* tally: this lane's finds (count-only mode; summed over the wave at the end of the kernel) or
- * the fill of the hit buffer (record mode, wave-uniform).  DIRECT (4-gram kernel, narrow
- * alphabets): no LDS buffer -- `hits` is the wave's region of the item buffer itself, the tally
- * its fill, a hit a plain store (what one batch reports lies side by side); Ep = the LDS copy of
- * E for the out-of-line overflow path. */
+/* the batch does not fit what is left of the chunk (or the chunk straddles the capacity): out of
+ * line.  Fills the chunk, reserves the next one, returns the slots used in the current chunk. */
+__device__ __noinline__ uint32_t
+emit_records_slow (const EmitCtx *Ep, WaveRec *W, uint32_t used, bool hit, uint32_t p, uint32_t length, uint32_t kw) {
+  const EmitCtx &E = *Ep;
+  const uint64_t m = __ballot (hit);
+  const uint32_t total = (uint32_t)__popcll (m), rank = rank_below (m);
+  const uint32_t lane = lane_id ();
+  unsigned long long base = ((unsigned long long)W->base_hi << 32) | W->base_lo;
+  const uint32_t room = W->have ? REC_CHUNK - used : 0u;
+  const uint64_t gp = E.pos_base + p;
+  const uint4 rec = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), length, kw);
+  if (hit && rank < room) {
+    uint4 *a = record_address (E, base + used + rank);
+    if (a)
+      *a = rec;
+  }
+  if (total <= room)
+    return used + total;
+  /* next chunk: one atomic for the wave */
+  unsigned long long nb = 0;
+  if (lane == 0)
+    nb = atomicAdd (E.count, (unsigned long long)REC_CHUNK);
+  nb = ((unsigned long long)__shfl ((uint32_t)(nb >> 32), 0, WAVE) << 32) | __shfl ((uint32_t)nb, 0, WAVE);
+  if (hit && rank >= room) {
+    uint4 *a = record_address (E, nb + (rank - room));
+    if (a)
+      *a = rec;
+  }
+  if (lane == 0) {
+    const bool below = nb + REC_CHUNK <= E.capacity;
+    const bool above = nb >= E.capacity && nb - E.capacity + REC_CHUNK <= E.spill_slots;
+    const uint64_t dst = below ? reinterpret_cast<uint64_t> (&E.records[nb]) : (above ? reinterpret_cast<uint64_t> (E.spill + (nb - E.capacity)) : 0ull);
+    W->dst_lo = (uint32_t)dst;
+    W->dst_hi = (uint32_t)(dst >> 32);
+    W->base_lo = (uint32_t)nb;
+    W->base_hi = (uint32_t)(nb >> 32);
+    W->limit = (below || above) ? REC_CHUNK : 0u;
+    W->have = 1;
+  }
+  return total - room;
+}
+
+/* Closes the holes the waves of a scan kernel left in their last chunks (RecHole, one per wave):
+ * with T = the counter (slots reserved so far) and H = the holes' total length, the records are
+ * the filled slots of [0, T) and there are C = T - H of them; those at C or beyond (in the
+ * caller's buffer or, past its capacity, in the spill area) move into the holes below C, the k-th
+ * hole slot taking the k-th such record, and the counter is rewound to C.
+ * Every block sorts the holes by first slot in LDS (bitonic, <= 4,096 keys of start << 11 | length),
+ * takes their prefix sums P, and handles the holes b, b + gridDim.x, ...: target = start_i + t is
+ * hole slot number k = P[i] + t; its source is the filled slot of rank (C - M) + k (M = hole slots
+ * below C), found by bisection on G[i] = start_i - P[i] = filled slots in front of hole i. */
+constexpr int CLOSE_THREADS = 1024;
+__global__ __launch_bounds__ (CLOSE_THREADS) void
+close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t npow, unsigned int *ticket) {
+  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
+  unsigned long long *key = reinterpret_cast<unsigned long long *> (smem); /* [npow] */
+  uint32_t *P = reinterpret_cast<uint32_t *> (smem + (size_t)npow * 8);    /* [npow + 1] exclusive prefix of the lengths, then spare */
+  __shared__ unsigned long long s_T;
+  __shared__ uint32_t s_part[CLOSE_THREADS / WAVE];
+  __shared__ uint32_t s_M;
+  const uint32_t tid = threadIdx.x;
+  constexpr unsigned long long PAD = ~0ull << 11;
+  for (uint32_t i = tid; i < npow; i += CLOSE_THREADS) {
+    unsigned long long k = PAD;
+    if (i < n_waves) {
+      const RecHole h = holes[i];
+      if (h.len)
+        k = (((unsigned long long)h.start_hi << 32 | h.start_lo) << 11) | h.len;
+    }
+    key[i] = k;
+  }
+  if (tid == 0)
+    s_T = __hip_atomic_load (E.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads ();
+  for (uint32_t k = 2; k <= npow; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = tid; i < npow; i += CLOSE_THREADS) {
+        const uint32_t o = i ^ j;
+        if (o > i) {
+          const unsigned long long a = key[i], b = key[o];
+          if ((a > b) == ((i & k) == 0)) {
+            key[i] = b;
+            key[o] = a;
+          }
+        }
+      }
+      __syncthreads ();
+    }
+  /* exclusive prefix of the lengths: every thread sums a run of npow / THREADS (>= 1) keys,
+   * the runs' sums are scanned by wave and block */
+  const uint32_t per = npow >= CLOSE_THREADS ? npow / CLOSE_THREADS : 1;
+  uint32_t run = 0;
+  for (uint32_t q = 0; q < per; q++) {
+    const uint32_t i = tid * per + q;
+    if (i < npow)
+      run += (uint32_t)(key[i] & 2047u);
+  }
+  const uint32_t incl = wave_incl_scan (run);
+  if ((tid & (WAVE - 1)) == WAVE - 1)
+    s_part[tid / WAVE] = incl;
+  __syncthreads ();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (int w = 0; w < CLOSE_THREADS / WAVE; w++) {
+      const uint32_t v = s_part[w];
+      s_part[w] = acc;
+      acc += v;
+    }
+    P[npow] = acc;
+  }
+  __syncthreads ();
+  {
+    uint32_t acc = s_part[tid / WAVE] + incl - run;
+    for (uint32_t q = 0; q < per; q++) {
+      const uint32_t i = tid * per + q;
+      if (i < npow) {
+        P[i] = acc;
+        acc += (uint32_t)(key[i] & 2047u);
+      }
+    }
+  }
+  __syncthreads ();
+  const unsigned long long T = s_T, H = P[npow], C = T - H;
+  /* M: hole slots below C */
+  uint32_t mine = 0;
+  for (uint32_t i = tid; i < npow; i += CLOSE_THREADS) {
+    const unsigned long long st = key[i] >> 11;
+    const uint32_t len = (uint32_t)(key[i] & 2047u);
+    if (len && st < C)
+      mine += C - st < len ? (uint32_t)(C - st) : len;
+  }
+  const uint32_t mi = wave_incl_scan (mine);
+  __syncthreads ();
+  if ((tid & (WAVE - 1)) == WAVE - 1)
+    s_part[tid / WAVE] = mi;
+  __syncthreads ();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (int w = 0; w < CLOSE_THREADS / WAVE; w++)
+      acc += s_part[w];
+    s_M = acc;
+  }
+  __syncthreads ();
+  const unsigned long long first_rank = C - s_M; /* rank (among the filled slots) of the first record at C or beyond */
+  for (uint32_t i = blockIdx.x; i < npow; i += gridDim.x) {
+    const unsigned long long st = key[i] >> 11;
+    const uint32_t len = (uint32_t)(key[i] & 2047u);
+    if (!len || st >= C)
+      continue;
+    const uint32_t clipped = C - st < len ? (uint32_t)(C - st) : len;
+    for (uint32_t t = tid; t < clipped; t += CLOSE_THREADS) {
+      const unsigned long long r = first_rank + P[i] + t;
+      /* holes in front of the filled slot of rank r: those with G = start - P <= r (G ascends) */
+      uint32_t lo = 0, hi = npow;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        const unsigned long long g = (key[mid] >> 11) - P[mid];
+        if ((key[mid] & 2047u) != 0 ? g <= r : false) /* (the padding sorts last and is in front of nothing) */
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      const unsigned long long src = r + P[lo];
+      const uint4 *from = record_address (E, src);
+      if (from && st + t < E.capacity)
+        *reinterpret_cast<uint4 *> (&E.records[st + t]) = *from;
+    }
+  }
+  /* the block that finishes last rewinds the counter: every block has read T by then */
+  __syncthreads ();
+  if (tid == 0) {
+    if (atomicAdd (ticket, 1u) == gridDim.x - 1) {
+      *ticket = 0;
+      __hip_atomic_store (E.count, C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+/* tally: this lane's finds (count-only mode; summed over the wave at the end of the kernel), the
+ * fill of the LDS hit buffer (record mode, wave-uniform), or -- DIRECT (4-gram kernel, narrow
+ * alphabets) -- the slots used of the wave's current chunk of records: `hits` is then the wave's
+ * WaveRec in LDS, `kw` / `length` the record's second half (other modes: `kw` is the hit's word --
+ * a terminal state or a HIT_KW / HIT_LEN4 word -- and `length` is not looked at); Ep = the LDS copy
+ * of E for the out-of-line path. */
+/* the wave's chunk state as the scan kernel keeps it in scalar registers between batches (a
+ * pipeline step that asked LDS for it every time paid an LDS round trip per batch: the scan kernel
+ * 2.12 -> 2.36 ms per 2 GiB of config 3); reloaded from the WaveRec after the out-of-line paths */
+struct RecState {
+  unsigned long long dst; /* address of slot 0 of the current chunk */
+  uint32_t limit;
+};
+__device__ __forceinline__ RecState
+rec_state_load (const uint2 *hits) {
+  const WaveRec *W = reinterpret_cast<const WaveRec *> (hits);
+  RecState r;
+  r.dst = ((unsigned long long)uniform (W->dst_hi) << 32) | uniform (W->dst_lo);
+  r.limit = uniform (W->limit);
+  return r;
+}
+
 template <bool COUNT_ONLY, bool DIRECT = false>
 __device__ __forceinline__ void
-emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t lane, uint2 *hits, unsigned long long &tally,
-                const EmitCtx *Ep = nullptr, uint32_t capacity = 0) {
+emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t kw, uint32_t length, uint32_t lane, uint2 *hits, unsigned long long &tally,
+                const EmitCtx *Ep = nullptr, RecState *rs = nullptr) {
   if (COUNT_ONLY) {
     tally += hit ? 1u : 0u;
     return;
@@ -216,12 +431,21 @@ emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t la
     const uint32_t total = (uint32_t)__popcll (m);
     uint32_t hn = (uint32_t)tally;
     if (DIRECT) {
-      if (hn + total <= capacity) {
-        if (hit)
-          hits[hn + rank_below (m)] = make_uint2 (p, st);
+      WaveRec *W = reinterpret_cast<WaveRec *> (hits);
+      RecState here = rs ? *rs : rec_state_load (hits);
+      if (hn + total <= here.limit) {
+        /* the chunk's slot 0 + (used + rank) * 16: a wave-uniform base and a 32-bit offset */
+        if (hit) {
+          const uint64_t gp = E.pos_base + p;
+          const uint32_t off = (hn + rank_below (m)) << 4;
+          *reinterpret_cast<uint4 *> (reinterpret_cast<unsigned char *> (here.dst) + off) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), length, kw);
+        }
         tally = hn + total;
-      } else
-        emit_overflow (Ep, hit, p, st);
+      } else {
+        tally = emit_records_slow (Ep, W, hn, hit, p, length, kw);
+        if (rs)
+          *rs = rec_state_load (hits);
+      }
       return;
     }
     if (hn + total > WAVE) {
@@ -229,7 +453,7 @@ emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t la
       hn = 0;
     }
     if (hit)
-      hits[hn + rank_below (m)] = make_uint2 (p, st);
+      hits[hn + rank_below (m)] = make_uint2 (p, kw);
     tally = hn + total;
   }
 }
@@ -243,8 +467,9 @@ emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t st, uint32_t la
  * (The structs come by pointer to copies the caller makes on the spot: taking the address of the
  * kernel's own K and E would move them from scalar registers to scratch memory for the whole
  * kernel -- measured 2x on the main loop.) */
-constexpr uint32_t WALK_CTX_K = 128, WALK_CTX_BYTES = 16 + 128 + 256; /* LDS after the tile counter: StartsK, EmitCtx */
-static_assert (sizeof (StartsK) <= WALK_CTX_K && sizeof (EmitCtx) <= 256, "walk context does not fit its LDS slot");
+constexpr uint32_t WALK_CTX_K = 128, WALK_CTX_E = 256; /* LDS after the tile counter: StartsK, EmitCtx, one WaveRec per wave */
+constexpr uint32_t WALK_CTX_BYTES = 16 + WALK_CTX_K + WALK_CTX_E + (SPARSE_THREADS / WAVE) * sizeof (WaveRec);
+static_assert (sizeof (StartsK) <= WALK_CTX_K && sizeof (EmitCtx) <= WALK_CTX_E, "walk context does not fit its LDS slot");
 constexpr uint32_t WI_REPORTED = 0x80000000u; /* what ends in this state has been reported by the caller */
 constexpr uint32_t WI_RECORD = 0x40000000u;   /* 4-gram kernel: the index is a record index already (StartsK::remap) */
 template <typename SYM, bool COUNT_ONLY, int GRAM = 0>
@@ -281,11 +506,13 @@ walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue
   }
   const bool more = alive && p + 1 < E.n;
   const uint32_t c1 = more ? (uint32_t)text[p + 1] : 0u;
-  emit_terminals<COUNT_ONLY, GRAM == 2> (E, regular && !(it.y & WI_REPORTED) && ra.w != 0 && p >= E.emit_from, p, GRAM ? ra.x : st, lane,
-                                         hits, counted, Ep, K.region_items);
+  /* (4-gram kernels: word 1 of a record is n_edges | depth << 16, word 3 the keyword id + 1 of a
+   * terminal state -- what a record written on the spot needs; fill_gram_tables) */
+  emit_terminals<COUNT_ONLY, GRAM == 2> (E, regular && !(it.y & WI_REPORTED) && ra.w != 0 && p >= E.emit_from, p,
+                                         GRAM == 2 ? ra.w - 1u : (GRAM ? ra.x : st), ra.y >> 16, lane, hits, counted, Ep);
   uint32_t nx = NONE;
   if (more && regular) {
-    const uint32_t ne = ra.y;
+    const uint32_t ne = GRAM ? ra.y & 0xFFFFu : ra.y;
     if (ne >= 1 && rb.x == c1)
       nx = rb.y;
     else if (ne >= 2 && rb.z == c1)
@@ -358,7 +585,7 @@ struct TileShare {
     begin = A.range_begin;
     static_tiles = A.static_end - A.range_begin;
     blk_tiles = blockIdx.x < static_tiles ? (static_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const uint32_t cls = blockIdx.x * POOL_CLASSES / gridDim.x;
+    const uint32_t cls = blockIdx.x * A.pool_classes / gridDim.x;
     cls_begin = A.static_end + cls * A.pool_class_tiles;
     cls_tiles = cls_begin >= A.range_end ? 0 : (A.range_end - cls_begin < A.pool_class_tiles ? A.range_end - cls_begin : A.pool_class_tiles);
     cls_ctr = A.pool_ctr + cls * POOL_CTR_STRIDE;

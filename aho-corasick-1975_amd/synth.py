@@ -80,3 +80,31 @@ def device_text(n, kw_data, kw_off, begin=0, sym_bytes=1, vocab=32768, device=No
     _check(lib().acm_gpu_synth_text(device.index or 0, out.data_ptr(), n, begin, sym_bytes, vocab, kd.data_ptr(),
                                     ko.data_ptr(), len(kw_off) - 1, st), "acm_gpu_synth_text")
     return out
+
+
+def device_digest(rec, n, below=None, at_least=None):
+    """(count, digest) of the first n records of an int64 [cap, 2] device buffer, optionally only
+    those with at_least <= end_pos < below.  digest = sum of splitmix64 ((end_pos * 1315423911) ^
+    (length << 40) ^ (keyword_id + 1)) mod 2^64 (oracle/ac_oracle.c record_hash)
+    -- order-independent; int64 arithmetic wraps, the logical right shifts are spelled with a mask."""
+    r = rec[:n]
+    pos, lo = r[:, 0], r[:, 1]
+    if below is not None or at_least is not None:
+        keep = (pos < below) if below is not None else (pos >= at_least)
+        if below is not None and at_least is not None:
+            keep = keep & (pos >= at_least)
+        pos, lo = pos[keep], lo[keep]
+    length = lo & 0xFFFFFFFF
+    kw = (lo >> 32) & 0xFFFFFFFF
+
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def i64(c):  # python int -> the int64 with the same bit pattern
+        return c - (1 << 64) if c >= (1 << 63) else c
+    x = (pos * 1315423911) ^ (length << 40) ^ (kw + 1)
+    x = x + i64(0x9E3779B97F4A7C15)
+    x = (x ^ lsr(x, 30)) * i64(0xBF58476D1CE4E5B9)
+    x = (x ^ lsr(x, 27)) * i64(0x94D049BB133111EB)
+    x = x ^ lsr(x, 31)
+    return int(pos.numel()), int(x.sum().item()) & ((1 << 64) - 1)

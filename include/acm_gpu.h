@@ -157,11 +157,7 @@ typedef struct {
                             3 = sparse automaton walk when the environment says ACM_GPU_SPARSE=walk;
                             5 = 4-gram sieve kernel: byte dictionaries whose hot rows outgrow LDS (more than about
                             1,300 keywords over a-z) with some keyword of 4 symbols or more
-                            (ACM_GPU_GRAM=0: kernel 1 instead, ACM_GPU_GRAM=2: kernel 5 whenever possible);
-                            6 = trigram sieve kernel, only when the environment says ACM_GPU_SIEVE=1 (an experiment kept
-                            for the record: slower than kernel 1): byte dictionaries over at most 29 distinct symbols whose
-                            keywords all have 4 symbols or more and start with few different trigrams; trigram bits once per
-                            LDS bank, conflict-free, then kernel 5's later stages */
+                            (ACM_GPU_GRAM=0: kernel 1 instead, ACM_GPU_GRAM=2: kernel 5 whenever possible) */
   uint32_t entry_bytes;  /* dense entries: 2 or 4 */
   uint32_t width;        /* dense row width */
   uint32_t dense_rows;   /* rows resident in HBM */
@@ -175,6 +171,9 @@ typedef struct {
   uint64_t table_bytes;  /* device bytes held by the plan */
   uint32_t delta_keywords; /* keywords added since the tables were made, held by the delta plan (acm_gpu_plan_update) */
   uint32_t merges;         /* updates that rebuilt the tables (the delta had outgrown its share) */
+  uint32_t records_direct; /* 1: the scan kernel writes the 16-byte records itself (kernel 5 on alphabets of at most 29
+                              symbols; kernel 2); 0: it parks 8-byte items / hits that a second kernel turns into records */
+  uint32_t reserved;
 } ACMPlanInfo;
 
 /* Flattens `machine` and uploads the tables to `device`.  The plan is a snapshot: keywords
@@ -258,6 +257,40 @@ int acm_gpu_stream_feed (ACMStream *stream, const void *text, uint64_t n_symbols
 int acm_gpu_stream_finish (ACMStream *stream, ACMRecord *records, uint64_t capacity, uint64_t *n_found);
 void acm_gpu_stream_close (ACMStream *stream);
 
+/* ------------------------------------------------------------------ several GPUs of one node, one process
+ * The reference's model for parallel work is one shared read-only machine and one cursor per worker
+ * (/root/reference/README.md:364, aho_corasick.h:70: the caller owns the `const ACState *`).  The
+ * cursor after any symbol depends on the last lmax symbols only, so a text splits into R contiguous
+ * shards that are scanned independently: shard r owns [r N / R, (r + 1) N / R),
+ * starts from the root lmax - 1 symbols earlier (rounded down to a 16-byte boundary of the text)
+ * and reports the matches that END inside its range.  An ACMMulti holds one plan per distinct
+ * device (tables replicated) and one stream per device; shard r runs on devices[r] -- a device may
+ * appear several times (shards of one device run one after the other on its stream), so that
+ * `devices = {0,0,0,0,0,0,0,0}` exercises on one GPU everything but the peer copies.
+ * The one exchange step: every shard's records are put in canonical order where they were found
+ * and copied into their place in one buffer on devices[0] -- hipMemcpyPeerAsync from the other
+ * devices (xGMI is point-to-point: these are the direct peer-to-root transfers of SURVEY.md 8e, one
+ * per link), a device-to-device copy for shards of devices[0] itself.  Shards own increasing
+ * position ranges: their concatenation in shard order IS the canonical order of the whole text. */
+typedef struct ACMMulti ACMMulti;
+int acm_gpu_multi_create (ACMachine *machine, const int *devices, int n_shards, ACMMulti **out);
+void acm_gpu_multi_destroy (ACMMulti *multi);
+/* [read_begin, own_end) is what shard `shard` of a text of n_symbols reads, [own_begin, own_end) where its matches end */
+int acm_gpu_multi_shard_bounds (const ACMMulti *multi, uint64_t n_symbols, int shard, uint64_t *read_begin,
+                                uint64_t *own_begin, uint64_t *own_end);
+/* Text in host memory: the shards are uploaded to their devices, scanned, ordered, gathered on
+ * devices[0] and copied to `records` (canonical order of the whole text).  Blocking.
+ * ACM_GPU_E_OVERFLOW with *n_found = the capacity needed when `capacity` is too small. */
+int acm_gpu_multi_scan_host (ACMMulti *multi, const void *text, uint64_t n_symbols, ACMRecord *records,
+                             uint64_t capacity, uint64_t *n_found);
+/* Shards already resident: d_shard_text[r] is a buffer on devices[r] (16-byte aligned) holding the
+ * symbols [read_begin_r, own_end_r) of acm_gpu_multi_shard_bounds.  The records of the whole text
+ * arrive in canonical order in d_records, a buffer of `capacity` records on devices[0]; *n_found
+ * (host) = their number, which may exceed capacity (ACM_GPU_E_OVERFLOW: nothing dropped silently).
+ * Blocking. */
+int acm_gpu_multi_scan_device (ACMMulti *multi, const void *const *d_shard_text, uint64_t n_symbols,
+                               ACMRecord *d_records, uint64_t capacity, uint64_t *n_found);
+
 /* Waits for the plan's device and reports ACM_GPU_E_INTERNAL if a device-side consistency check
  * ever failed during its scans (never expected), else ACM_GPU_OK. */
 int acm_gpu_plan_status (ACMPlan *plan);
@@ -267,6 +300,10 @@ int acm_gpu_plan_status (ACMPlan *plan);
  * Reading synchronises on the recorded events. */
 int acm_gpu_plan_timing (ACMPlan *plan, int enable);
 int acm_gpu_plan_timing_read (ACMPlan *plan, double *total_ms, uint64_t *launches);
+/* the same, and beside the scan kernels' time (scan_ms) the time from the start of each scan kernel
+ * to the end of what its launch enqueues behind it -- the expansion of parked items / hits into
+ * records, or the closing of the holes in a record buffer the scan kernel wrote itself (all_ms) */
+int acm_gpu_plan_timing_read_all (ACMPlan *plan, double *scan_ms, double *all_ms, uint64_t *launches);
 
 /* ------------------------------------------------------------------ synthetic workload (bench/test tooling)
  * text[i] = 'a' + sm(i + 42) % 26, one keyword planted per 4096-symbol block.

@@ -537,6 +537,7 @@ struct mt_job {
   const unsigned char *text;
   uint64_t begin, end, warm;
   size_t sym_size;
+  uint64_t pos_base; /* added to a record's position in the digest (a piece of a longer text) */
   uint64_t found, digest;
 };
 
@@ -552,7 +553,7 @@ mt_worker (void *arg) {
       continue;
     for (size_t k = 0; k < nb; k++) {
       orc_get_match (cur, k, &h);
-      j->digest += record_hash (i, (uint32_t)h.length, (uint32_t)((uintptr_t)h.value - 1));
+      j->digest += record_hash (j->pos_base + i, (uint32_t)h.length, (uint32_t)((uintptr_t)h.value - 1));
       j->found++;
     }
   }
@@ -560,9 +561,13 @@ mt_worker (void *arg) {
   return 0;
 }
 
+/* A piece text[0 .. n) of a longer text whose first symbol has global index pos_base: matches that
+ * end before emit_from are not counted (the piece starts with an overlap of lmax - 1 symbols of
+ * its predecessor, scanned as a warm-up only), the digest is taken over global positions -- it is
+ * a sum over records, so the digests of the pieces of a text add up to the digest of the whole. */
 uint64_t
-orc_scan_mt (orc_machine *m, const void *text, uint64_t n, size_t sym_size, size_t lmax,
-             int threads, uint64_t *digest) {
+orc_scan_mt_at (orc_machine *m, const void *text, uint64_t n, size_t sym_size, size_t lmax,
+                int threads, uint64_t pos_base, uint64_t emit_from, uint64_t *digest) {
   if (threads < 1)
     threads = 1;
   if (m->variant == ORC_AC75)
@@ -575,8 +580,11 @@ orc_scan_mt (orc_machine *m, const void *text, uint64_t n, size_t sym_size, size
     jobs[t].m = m;
     jobs[t].text = text;
     jobs[t].sym_size = sym_size;
-    jobs[t].begin = n * (uint64_t)t / (uint64_t)threads;
-    jobs[t].end = n * (uint64_t)(t + 1) / (uint64_t)threads;
+    if (emit_from > n)
+      emit_from = n;
+    jobs[t].pos_base = pos_base;
+    jobs[t].begin = emit_from + (n - emit_from) * (uint64_t)t / (uint64_t)threads;
+    jobs[t].end = emit_from + (n - emit_from) * (uint64_t)(t + 1) / (uint64_t)threads;
     jobs[t].warm = jobs[t].begin > overlap ? jobs[t].begin - overlap : 0;
     if (threads == 1)
       mt_worker (&jobs[t]);
@@ -595,4 +603,10 @@ orc_scan_mt (orc_machine *m, const void *text, uint64_t n, size_t sym_size, size
   if (digest)
     *digest = d;
   return found;
+}
+
+uint64_t
+orc_scan_mt (orc_machine *m, const void *text, uint64_t n, size_t sym_size, size_t lmax,
+             int threads, uint64_t *digest) {
+  return orc_scan_mt_at (m, text, n, sym_size, lmax, threads, 0, 0, digest);
 }

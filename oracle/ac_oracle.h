@@ -95,6 +95,9 @@ uint64_t orc_digest (const orc_record *r, uint64_t n);
  * writes the digest; does not store records.  Used by bench.py's cpu_baseline leg. */
 uint64_t orc_scan_mt (orc_machine *m, const void *text, uint64_t n, size_t sym_size,
                       size_t lmax, int threads, uint64_t *digest);
+/* the same over a piece of a longer text: global positions in the digest, nothing reported before emit_from */
+uint64_t orc_scan_mt_at (orc_machine *m, const void *text, uint64_t n, size_t sym_size, size_t lmax,
+                         int threads, uint64_t pos_base, uint64_t emit_from, uint64_t *digest);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,8 @@ def lib():
     L.orc_digest.argtypes = [vp, u64]
     L.orc_scan_mt.restype = u64
     L.orc_scan_mt.argtypes = [vp, vp, u64, sz, sz, C.c_int, C.POINTER(u64)]
+    L.orc_scan_mt_at.restype = u64
+    L.orc_scan_mt_at.argtypes = [vp, vp, u64, sz, sz, C.c_int, u64, u64, C.POINTER(u64)]
     L.orc_cmp_default.restype = C.c_int
     _lib = L
     return L
@@ -186,6 +188,14 @@ class Oracle:
         t = self._text(text)
         d = C.c_uint64(0)
         n = self.L.orc_scan_mt(self.m, t.ctypes.data, t.size, self.sym_size, self.lmax, threads, C.byref(d))
+        return int(n), int(d.value)
+
+    def scan_mt_at(self, text, threads, pos_base, emit_from):
+        """(count, digest) of a piece of a longer text: global positions pos_base + i in the digest,
+        matches ending before emit_from (the overlap with the piece before) left out."""
+        t = self._text(text)
+        d = C.c_uint64(0)
+        n = self.L.orc_scan_mt_at(self.m, t.ctypes.data, t.size, self.sym_size, self.lmax, threads, pos_base, emit_from, C.byref(d))
         return int(n), int(d.value)
 
 
