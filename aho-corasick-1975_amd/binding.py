@@ -73,7 +73,7 @@ EXPORTS = [
     "acm_flat_dense_rows", "acm_flat_blob_bytes", "acm_flat_to_blob", "acm_flat_from_blob", "acm_flat_save",
     "acm_flat_load", "acm_flat_keyword", "acm_flatten_classes", "acm_gpu_plan_create_classes", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_update", "acm_gpu_plan_destroy",
     "acm_gpu_plan_info", "acm_gpu_scan_device", "acm_gpu_count_device", "acm_gpu_sort_tmp_bytes",
-    "acm_gpu_sort_records_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
+    "acm_gpu_sort_records_device", "acm_gpu_order_tmp_bytes", "acm_gpu_order_records_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
     "acm_gpu_plan_timing_read", "acm_gpu_plan_timing_read_all", "acm_gpu_plan_status", "acm_gpu_synth_text",
     "acm_gpu_stream_open", "acm_gpu_stream_feed", "acm_gpu_stream_finish", "acm_gpu_stream_close",
     "acm_gpu_multi_create", "acm_gpu_multi_destroy", "acm_gpu_multi_shard_bounds", "acm_gpu_multi_scan_host",
@@ -165,6 +165,10 @@ def lib():
     L.acm_gpu_sort_tmp_bytes.argtypes = [u64]
     L.acm_gpu_sort_records_device.restype = i32
     L.acm_gpu_sort_records_device.argtypes = [vp, vp, u64, vp, sz, vp]
+    L.acm_gpu_order_tmp_bytes.restype = sz
+    L.acm_gpu_order_tmp_bytes.argtypes = [vp, u64, u64]
+    L.acm_gpu_order_records_device.restype = i32
+    L.acm_gpu_order_records_device.argtypes = [vp, vp, u64, u64, u64, vp, sz, vp]
     L.acm_gpu_scan_host.restype = i32
     L.acm_gpu_scan_host.argtypes = [vp, vp, u64, u64, u64, vp, u64, C.POINTER(u64)]
     L.acm_scan.restype = i32
@@ -511,15 +515,24 @@ class Plan:
                                           self._stream()), "acm_gpu_count_device")
         return count
 
-    def sort(self, records, n):
-        """Canonical order (end_pos asc, length desc) of the first n records, in place."""
+    def sort(self, records, n, pos_lo=None, span=None):
+        """Canonical order (end_pos asc, length desc) of the first n records, in place.  With the
+        range of their positions given ([pos_lo, pos_lo + span): what a scan of `span` symbols with
+        pos_base = pos_lo leaves) acm_gpu_order_records_device orders them by position buckets and
+        LDS sorts; without, acm_gpu_sort_records_device radix-sorts them."""
         import torch
         if n <= 1:
             return records
-        tb = lib().acm_gpu_sort_tmp_bytes(n)
+        if pos_lo is None or span is None:
+            tb = lib().acm_gpu_sort_tmp_bytes(n)
+            tmp = torch.empty(tb, dtype=torch.uint8, device=records.device)
+            _check(lib().acm_gpu_sort_records_device(self.h, records.data_ptr(), n, tmp.data_ptr(), tb, self._stream()),
+                   "acm_gpu_sort_records_device")
+            return records
+        tb = lib().acm_gpu_order_tmp_bytes(self.h, n, span)
         tmp = torch.empty(tb, dtype=torch.uint8, device=records.device)
-        _check(lib().acm_gpu_sort_records_device(self.h, records.data_ptr(), n, tmp.data_ptr(), tb, self._stream()),
-               "acm_gpu_sort_records_device")
+        _check(lib().acm_gpu_order_records_device(self.h, records.data_ptr(), n, pos_lo, span, tmp.data_ptr(), tb, self._stream()),
+               "acm_gpu_order_records_device")
         return records
 
     def scan_sorted(self, text, n_symbols=None, emit_from=0, pos_base=0, capacity=None):
@@ -533,7 +546,8 @@ class Plan:
             if n > rec.shape[0]:
                 cap = n
                 continue
-            self.sort(rec, n)
+            ns = n_symbols if n_symbols is not None else text.numel() * text.element_size() // self.sym_size
+            self.sort(rec, n, pos_base, ns)
             self.status()
             return np.frombuffer(rec[:n].cpu().numpy().tobytes(), dtype=RECORD_DTYPE).copy()
 

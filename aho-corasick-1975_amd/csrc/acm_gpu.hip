@@ -22,6 +22,7 @@
  *   dev_emit.h    queue items -> records: put_outputs, walk_continuation, flush_queue,
  *                 expand_items_kernel (block-wide prefix sum, one atomic per round)
  *   dev_misc.h    classmap (comparator classes), patch (incremental updates), sort keys, synthetic text
+ *   dev_order.h   canonical order by position buckets + LDS sorts (three passes instead of a radix sort's eight)
  * No MFMA anywhere: this is byte/integer table walking bound by LDS lookups and HBM reads.
  */
 #include <hip/hip_runtime.h>
@@ -65,6 +66,13 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
 constexpr int QCAP = 128;           /* per-wave queue of (position, state) items, 8 B each */
 constexpr uint32_t GRAM_Q2 = 96;    /* 4-gram kernel: per-wave queue of walk candidates */
+/* 4-gram kernel: its first queue.  -DACM_GRAM_PUSH2=1 (experiment, measured 9.6 % SLOWER: 2.425
+ * against 2.213 ms per 2 GiB of config 3) builds the branch-free push of dev_gram.h, whose queue
+ * holds 63 waiting + 2 x 64 pushed items; the product is built without it */
+#ifndef ACM_GRAM_PUSH2
+#define ACM_GRAM_PUSH2 0
+#endif
+constexpr uint32_t GRAM_Q1 = ACM_GRAM_PUSH2 ? 192 : 128;
 constexpr uint32_t GRAM_NO_PEEK = 0xFFFFFFFFu; /* 4-gram kernel, GramK::g5peek: the state's record has to be looked at */
 constexpr int DENSE_THREADS = 1024; /* one workgroup per CU, 16 waves */
 /* dense kernel geometry: C = 64 bytes per lane-stream per tile, S = 2 streams per lane
@@ -159,6 +167,7 @@ constexpr uint32_t IT_OUT = 1u << 29;   /* report the outputs of the state itsel
 #include "dev_starts.h"
 #include "dev_gram.h"
 #include "dev_misc.h"
+#include "dev_order.h"
 
 } // namespace
 
@@ -275,6 +284,7 @@ struct ACMPlan {
    * the delta's keyword ids start at kw_base).  A replaced delta waits in `retired` until the
    * stream that may still be scanning with it has passed an event. */
   ACMPlan *delta = nullptr;
+  uint64_t delta_scanned = 0;    /* symbols scanned twice (plan, then delta) since this delta's first keyword came */
   uint32_t covered_keywords = 0; /* keywords of the machine this plan and its delta report */
   uint32_t kw_base = 0;          /* added to the keyword ids of this plan's records (delta plans) */
   uint32_t merges = 0;           /* updates that rebuilt everything */
@@ -581,13 +591,13 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     if (G.bloom) {
       auto set = [&] (uint32_t slot) { G.bloom[slot >> 5] |= 1u << (slot & 31); };
       if (fv.term_kw[st] != NONE) {
-        set (gram_bloom_slot (gram_bloom_hash (idx, 0), G.bloomT_bits));
-        set (gram_bloom_slot (gram_bloom_hash (idx, 1), G.bloomT_bits));
+        set (gram_bloom_slot (gram_bloom_hash (idx, 0), G.bloomT_bits, 0));
+        set (gram_bloom_slot (gram_bloom_hash (idx, 0), G.bloomT_bits, 1));
       }
       for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++) {
         const uint32_t c5 = fv.edge_sym[e] - G.lo;
-        set (G.bloomT_bits + gram_bloom_slot (gram_bloom_hash5 (idx, c5, 0), G.bloom5_bits));
-        set (G.bloomT_bits + gram_bloom_slot (gram_bloom_hash5 (idx, c5, 1), G.bloom5_bits));
+        set (G.bloomT_bits + gram_bloom_slot (gram_bloom_hash5 (idx, c5, 0), G.bloom5_bits, 0));
+        set (G.bloomT_bits + gram_bloom_slot (gram_bloom_hash5 (idx, c5, 0), G.bloom5_bits, 1));
       }
     }
   }
@@ -824,7 +834,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const char *bloom_env = getenv ("ACM_GPU_BLOOM"); /* 0: no Bloom filters (experiments) */
   if (gram && !gram_wide && n_depth4 >= 2048 && !(bloom_env && atoi (bloom_env) == 0)) {
     const uint32_t lds_cap = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
-    const uint32_t gq_bytes = (SPARSE_THREADS / WAVE) * ((gram_shorts ? 2 : 1) * QCAP + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
+    const uint32_t gq_bytes = (SPARSE_THREADS / WAVE) * ((gram_shorts ? QCAP : 0u) + GRAM_Q1 + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
     bloom_off = (g3_off + g3_bytes + 15) & ~15u;
     const uint64_t used = (uint64_t)bloom_off + gq_bytes + WALK_CTX_BYTES + 64;
     uint32_t n_term4 = 0, n_5 = 0;
@@ -1016,7 +1026,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   p->d_dstart = u32p (o_dstart);
   if (gram) {
     const uint32_t lds_total = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
-    const uint32_t gq = (SPARSE_THREADS / WAVE) * ((gram_shorts ? 2 : 1) * QCAP + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
+    const uint32_t gq = (SPARSE_THREADS / WAVE) * ((gram_shorts ? QCAP : 0u) + GRAM_Q1 + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
     const uint32_t bits_bytes = bloom5_bits ? bloom_off + bloom_bytes : g3_off + g3_bytes;
     if ((uint64_t)bits_bytes + gq + WALK_CTX_BYTES <= lds_total) {
       p->d_kw4 = u32p (o_kw4);
@@ -2237,6 +2247,7 @@ scan_plan (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   int rc = scan_impl<COUNT_ONLY> (p, d_text, n, emit_from, pos_base, d_records, capacity, d_count, st, true);
   if (!rc)
     rc = scan_impl<COUNT_ONLY> (p->delta, d_text, n, emit_from, pos_base, d_records, capacity, d_count, st, true, p->d_total);
+  p->delta_scanned += n; /* what acm_gpu_plan_update weighs against the cost of one plan of everything */
   if (!accumulate) { /* (also after a failure: the total must not leak into the next scan) */
     hipLaunchKernelGGL (finish_count_kernel, dim3 (1), dim3 (64), 0, st, p->d_total, reinterpret_cast<unsigned long long *> (d_count));
     HIP_TRY (hipGetLastError ());
@@ -2388,11 +2399,11 @@ acm_gpu_stream_finish (ACMStream *s, ACMRecord *records, uint64_t capacity, uint
   if (total > s->capacity || total > capacity)
     return ACM_GPU_E_OVERFLOW;
   if (total > 1) {
-    const size_t tb = acm_gpu_sort_tmp_bytes (total);
+    const size_t tb = acm_gpu_order_tmp_bytes (p, total, s->position);
     void *tmp = nullptr;
     if (hipMalloc (&tmp, tb) != hipSuccess)
       return ACM_GPU_E_NOMEM;
-    int rc = acm_gpu_sort_records_device (p, s->d_records, total, tmp, tb, s->compute);
+    int rc = acm_gpu_order_records_device (p, s->d_records, total, 0, s->position, tmp, tb, s->compute);
     if (!rc && hipStreamSynchronize (s->compute) != hipSuccess)
       rc = ACM_GPU_E_HIP;
     (void)hipFree (tmp);
@@ -2480,6 +2491,103 @@ acm_gpu_sort_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, vo
   return ACM_GPU_OK;
 }
 
+/* ---- canonical order of records whose positions lie in [pos_lo, pos_lo + span): dev_order.h */
+namespace {
+struct OrderPlan {
+  uint32_t wlog = 0, n_buckets = 0, len_bits = 1;
+  size_t o_hist = 0, o_cur = 0, o_rec = 0, o_cub = 0, cub_bytes = 0, total = 0;
+  bool ok = false;
+};
+OrderPlan
+order_layout (const ACMPlan *plan, uint64_t n, uint64_t span) {
+  OrderPlan L;
+  if (n == 0 || span == 0 || n >= (1ull << 31))
+    return L;
+  /* buckets of ORDER_POSITIONS positions (fewer when the whole range is shorter) */
+  uint32_t wlog = 0;
+  while ((2u << wlog) <= ORDER_POSITIONS && (1ull << wlog) < span)
+    wlog++;
+  const uint64_t nb = (span >> wlog) + 1;
+  uint32_t span_bits = 1, len_bits = 1;
+  while ((1ull << span_bits) < span && span_bits < 63)
+    span_bits++;
+  const uint32_t lmax = plan->finfo.lmax > (plan->delta ? plan->delta->finfo.lmax : 0) ? plan->finfo.lmax : (plan->delta ? plan->delta->finfo.lmax : 0);
+  while ((1u << len_bits) <= lmax)
+    len_bits++;
+  if (nb >= (1ull << 28) || span_bits + len_bits > 63 || wlog + len_bits > 31) /* (a bucket's keys are 32-bit) */
+    return L;
+  L.wlog = wlog;
+  L.n_buckets = (uint32_t)nb;
+  L.len_bits = len_bits;
+  size_t cub = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum (nullptr, cub, static_cast<uint32_t *> (nullptr), static_cast<uint32_t *> (nullptr), (int)(nb + 1), nullptr);
+  L.cub_bytes = cub;
+  size_t cur = 0;
+  L.o_hist = blob_reserve (cur, (nb + 1) * 4);
+  L.o_cur = blob_reserve (cur, (nb + 1) * 4);
+  L.o_rec = blob_reserve (cur, n * sizeof (ACMRecord));
+  L.o_cub = blob_reserve (cur, cub + 16);
+  L.total = cur + 256;
+  L.ok = true;
+  return L;
+}
+} // namespace
+
+extern "C" size_t
+acm_gpu_order_tmp_bytes (const ACMPlan *plan, uint64_t n, uint64_t span) {
+  if (!plan)
+    return 0;
+  const OrderPlan L = order_layout (plan, n, span);
+  const size_t radix = acm_gpu_sort_tmp_bytes (n);
+  return L.ok && L.total > radix ? L.total : radix; /* (room for the fallback either way) */
+}
+
+extern "C" int
+acm_gpu_order_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, uint64_t pos_lo, uint64_t span, void *d_tmp,
+                              size_t tmp_bytes, void *stream) {
+  if (!plan || (n && (!d_records || !d_tmp)))
+    return ACM_GPU_E_ARG;
+  if (n <= 1)
+    return ACM_GPU_OK;
+  if (tmp_bytes < acm_gpu_order_tmp_bytes (plan, n, span))
+    return ACM_GPU_E_ARG;
+  const OrderPlan L = order_layout (plan, n, span);
+  const char *env = getenv ("ACM_GPU_ORDER"); /* radix: always the radix sort (experiments, tests) */
+  if (!L.ok || (env && strcmp (env, "radix") == 0))
+    return acm_gpu_sort_records_device (plan, d_records, n, d_tmp, tmp_bytes, stream);
+  HIP_TRY (hipSetDevice (plan->device));
+  hipStream_t st = static_cast<hipStream_t> (stream);
+  unsigned char *t = static_cast<unsigned char *> (d_tmp);
+  uint32_t *hist = reinterpret_cast<uint32_t *> (t + L.o_hist), *cur = reinterpret_cast<uint32_t *> (t + L.o_cur);
+  ACMRecord *bucketed = reinterpret_cast<ACMRecord *> (t + L.o_rec);
+  OrderK K{};
+  K.in = d_records;
+  K.n = n;
+  K.pos_lo = pos_lo;
+  K.wlog = L.wlog;
+  K.n_buckets = L.n_buckets;
+  K.len_bits = L.len_bits;
+  K.error = plan->d_total ? reinterpret_cast<unsigned int *> (plan->d_total) + 3 : nullptr;
+  HIP_TRY (hipMemsetAsync (hist, 0, ((size_t)L.n_buckets + 1) * 4, st));
+  const uint64_t pieces = (n + ORDER_PIECE - 1) / ORDER_PIECE, pblocks = (pieces + ORDER_THREADS / WAVE - 1) / (ORDER_THREADS / WAVE);
+  const uint32_t grid = (uint32_t)(pblocks < (uint64_t)plan->cu_count * 8 ? pblocks : (uint64_t)plan->cu_count * 8);
+  hipLaunchKernelGGL (order_bucket_kernel<false>, dim3 (grid), dim3 (ORDER_THREADS), 0, st, K, hist, static_cast<ACMRecord *> (nullptr));
+  HIP_TRY (hipGetLastError ());
+  size_t cub = L.cub_bytes;
+  HIP_TRY (hipcub::DeviceScan::ExclusiveSum (t + L.o_cub, cub, hist, cur, (int)(L.n_buckets + 1), st));
+  /* `cur` = where every bucket begins (and, at n_buckets, ends): pass C reads it; pass B advances a copy */
+  HIP_TRY (hipMemcpyAsync (hist, cur, ((size_t)L.n_buckets + 1) * 4, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL (order_bucket_kernel<true>, dim3 (grid), dim3 (ORDER_THREADS), 0, st, K, hist, bucketed);
+  HIP_TRY (hipGetLastError ());
+  /* pass C: small buckets by a wave each, the others by a block each (each kernel skips the other's) */
+  const uint32_t sgrid = (uint32_t)((L.n_buckets + 3) / 4 < (uint32_t)plan->cu_count * 16 ? (L.n_buckets + 3) / 4 : (uint32_t)plan->cu_count * 16);
+  hipLaunchKernelGGL (order_small_kernel, dim3 (sgrid), dim3 (256), 0, st, K, cur, bucketed, d_records);
+  const uint32_t cgrid = (uint32_t)(L.n_buckets < (uint32_t)plan->cu_count * 8 ? L.n_buckets : (uint32_t)plan->cu_count * 8);
+  hipLaunchKernelGGL (order_count_kernel, dim3 (cgrid), dim3 (ORDER_COUNT_THREADS), 0, st, K, cur, bucketed, d_records);
+  HIP_TRY (hipGetLastError ());
+  return ACM_GPU_OK;
+}
+
 /* ------------------------------------------------------------------ host-buffer convenience */
 extern "C" int
 acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint64_t emit_from, uint64_t pos_base,
@@ -2524,9 +2632,9 @@ acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint64_t
     return ACM_GPU_E_OVERFLOW;
   }
   if (found > 1) {
-    size_t tb = acm_gpu_sort_tmp_bytes (found);
+    size_t tb = acm_gpu_order_tmp_bytes (plan, found, n_symbols);
     HOST_TRY (hipMalloc (&d_tmp, tb));
-    rc = acm_gpu_sort_records_device (plan, static_cast<ACMRecord *> (d_rec), found, d_tmp, tb, nullptr);
+    rc = acm_gpu_order_records_device (plan, static_cast<ACMRecord *> (d_rec), found, pos_base, n_symbols, d_tmp, tb, nullptr);
     if (rc) {
       cleanup ();
       return rc;
@@ -2743,9 +2851,9 @@ multi_scan (ACMMulti *mu, const void *const *d_text, uint64_t n, ACMRecord *d_ou
     MULTI_TRY (hipSetDevice (mu->dev[r]));
     hipStream_t st = mu->stream[s.slot];
     if (s.found > 1) {
-      const size_t tb = acm_gpu_sort_tmp_bytes (s.found);
+      const size_t tb = acm_gpu_order_tmp_bytes (mu->plan[s.slot], s.found, s.e - s.b);
       MULTI_TRY (hipMalloc (&s.tmp, tb));
-      rc = acm_gpu_sort_records_device (mu->plan[s.slot], s.rec, s.found, s.tmp, tb, st);
+      rc = acm_gpu_order_records_device (mu->plan[s.slot], s.rec, s.found, s.b, s.e - s.b, s.tmp, tb, st);
       if (rc) {
         cleanup ();
         return rc;
@@ -2899,14 +3007,20 @@ acm_gpu_plan_update (ACMPlan *plan, ACMachine *machine) {
     acm_internal_unlock (machine);
     return ACM_GPU_E_ARG; /* not the machine this plan came from */
   }
-  if (nk == plan->covered_keywords) {
+  /* A delta is a second pass over every text: on 1 GiB of config 2's text 0.57 ms per scan against
+   * 0.32 without one (tools/exp_delta_big.py: a dense delta pass runs at the dense kernel's rate
+   * whatever its size), while one plan of everything costs ~3.5 ms per 1,000 keywords once.  So the
+   * delta is also given up when the texts scanned with it add up to more than that is worth:
+   * 14 Gi symbols per 1,000 keywords of the dictionary (acm_scan asks after every scan). */
+  const bool scanned_enough = plan->delta && plan->delta_scanned > (uint64_t)(base_kw > 1000 ? base_kw : 1000) * (14ull << 20);
+  if (nk == plan->covered_keywords && !scanned_enough) {
     acm_internal_unlock (machine);
     plan->generation = gen;
     return ACM_GPU_OK;
   }
   const uint32_t threshold = base_kw / 8 > 256 ? base_kw / 8 : 256;
   const char *delta_env = getenv ("ACM_GPU_DELTA"); /* 0: always rebuild (experiments) */
-  if (nk - base_kw <= threshold && !(delta_env && atoi (delta_env) == 0)) {
+  if (nk - base_kw <= threshold && !scanned_enough && !(delta_env && atoi (delta_env) == 0)) {
     /* the new keywords into a machine of their own: same comparator, the main machine's letters */
     CMP_TYPE cmp;
     void *cmp_arg;
@@ -2992,8 +3106,9 @@ acm_scan (ACMachine *machine, const void *text, uint64_t n_symbols, ACMRecord *r
   void **slot = acm_internal_plan_slot (machine);
   ACMPlan *plan = static_cast<ACMPlan *> (*slot);
   int rc = ACM_GPU_OK;
-  if (plan && plan->generation != acm_internal_generation (machine))
-    rc = acm_gpu_plan_update (plan, machine);
+  if (plan && (plan->generation != acm_internal_generation (machine) ||
+               (plan->delta && plan->delta_scanned > (uint64_t)(plan->finfo.n_keywords > 1000 ? plan->finfo.n_keywords : 1000) * (14ull << 20))))
+    rc = acm_gpu_plan_update (plan, machine); /* new keywords, or a delta that has cost more second passes than one plan of everything */
   if (!rc && !plan) {
     int device = 0;
     if (const char *e = getenv ("ACM_GPU_DEVICE"))

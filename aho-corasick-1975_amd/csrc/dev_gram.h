@@ -93,10 +93,14 @@ __host__ __device__ __forceinline__ uint32_t
 gram_bloom_hash5 (uint32_t idx, uint32_t c5, int which) {
   return gram_bloom_hash (idx, which) + c5 * (which ? BLOOM_D2 : BLOOM_D1);
 }
+/* Both bits of a key lie in ONE word (a blocked filter: one LDS read per key instead of two, and
+ * half the address arithmetic; the false-positive rate of a filter this full -- 5 to 11 of a word's
+ * 32 bits set -- is the same within a tenth): the word from the hash's high bits scaled to the
+ * filter's words, the bits from its bits 0-4 and 5-9 (`second`). */
 __host__ __forceinline__ uint32_t
-gram_bloom_slot (uint32_t h, uint32_t m) {
+gram_bloom_slot (uint32_t h, uint32_t m, int second) {
   const uint32_t word = (uint32_t)(((uint64_t)(h & 0xFFFFFFu) * ((m / 32) << 8)) >> 32);
-  return word * 32 + (h & 31u);
+  return word * 32 + ((second ? h >> 5 : h) & 31u);
 }
 __device__ __forceinline__ uint32_t
 mul_hi_u24 (uint32_t a, uint32_t b) { /* bits 32..47 of the product of the operands' low 24 bits */
@@ -132,7 +136,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
    * that is more than 33), short-keyword queue (QCAP, SHORTS only), hit buffer (wide alphabets) */
   constexpr bool DIRECT = !WIDE; /* narrow alphabets: 16-byte records straight into the caller's buffer (dev_starts.h: WaveRec), no hits */
   constexpr uint32_t HB = DIRECT ? 0u : HITS_STRIDE;
-  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * ((NQ - 1) * QCAP + GRAM_Q2 + HB) * 8);
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (GRAM_Q1 + GRAM_Q2 + (NQ - 2) * QCAP + HB) * 8);
   StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4); /* see scan_starts_kernel */
   EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
   WaveRec *Ws = reinterpret_cast<WaveRec *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K + WALK_CTX_E); /* one per wave */
@@ -152,12 +156,12 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
 
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint32_t wib = uniform (threadIdx.x / WAVE);
-  uint2 *q1 = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
-  uint2 *q2 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * QCAP + wib * GRAM_Q2;
-  uint2 *q3 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * (QCAP + GRAM_Q2) + wib * QCAP; /* SHORTS only */
+  uint2 *q1 = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * GRAM_Q1;
+  uint2 *q2 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * GRAM_Q1 + wib * GRAM_Q2;
+  uint2 *q3 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * (GRAM_Q1 + GRAM_Q2) + wib * QCAP; /* SHORTS only */
   const uint32_t wave_id = blockIdx.x * WAVES + wib;
   uint2 *hits = DIRECT ? reinterpret_cast<uint2 *> (Ws + wib)
-                       : reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * ((NQ - 1) * QCAP + GRAM_Q2) + wib * HITS_STRIDE + 2;
+                       : reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * (GRAM_Q1 + GRAM_Q2 + (NQ - 2) * QCAP) + wib * HITS_STRIDE + 2;
   if (!DIRECT)
     hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
   else if (lane == 0) {
@@ -171,6 +175,9 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   const TileShare share (A);
   const uint32_t last_blk = (A.n - 1) / 16;
   uint32_t qn1 = 0, qn2 = 0, qn3 = 0;
+  uint32_t fill1 = 0; /* narrow alphabets: the first queue's fill as the pushes keep it, in a vector register */
+  asm volatile ("" : "+v"(fill1));
+  const uint32_t q1_lds = (uint32_t)(uintptr_t)(K.queue_off + wib * GRAM_Q1 * 8u); /* LDS address of this wave's first queue (LDS starts at 0: no static LDS here) */
   unsigned long long counted = 0;
   RecState rs = { 0ull, 0u }; /* DIRECT: the wave's chunk of records (no chunk yet) */
   /* batches of the first queue whose records are in flight: a pipeline of GRAM_DEPTH batches
@@ -333,15 +340,16 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       auto lds_word = [&] (uint32_t byte_off) -> uint32_t {
         return *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (byte_off);
       };
-      const uint32_t h1 = __umul24 (idx, BLOOM_C1), h2 = __umul24 (idx, BLOOM_C2);
-      const uint32_t h3 = mad_u24 (c5, BLOOM_D1, h1), h4 = mad_u24 (c5, BLOOM_D2, h2);
-      const uint32_t w1 = lds_word (offT + mul_hi_u24 (h1, scaleT) * 4u), w2 = lds_word (offT + mul_hi_u24 (h2, scaleT) * 4u);
-      const uint32_t w3 = lds_word (off5 + mul_hi_u24 (h3, scale5) * 4u), w4 = lds_word (off5 + mul_hi_u24 (h4, scale5) * 4u);
+      /* one word per filter: both bits of a key lie in it (gram_bloom_slot) */
+      const uint32_t h1 = __umul24 (idx, BLOOM_C1);
+      const uint32_t h3 = mad_u24 (c5, BLOOM_D1, h1);
+      const uint32_t w1 = lds_word (offT + mul_hi_u24 (h1, scaleT) * 4u);
+      const uint32_t w3 = lds_word (off5 + mul_hi_u24 (h3, scale5) * 4u);
       const uint32_t word = lds_word ((idx >> 5) * 4u);
       consume_pass ();
       pipeline_shift ();
       pend_item[GRAM_DEPTH - 1] = it;
-      const uint32_t tf = ((w1 >> (h1 & 31u)) & (w2 >> (h2 & 31u))) | ((w3 >> (h3 & 31u)) & (w4 >> (h4 & 31u))) | (K.bloom5_bits ? 0u : 1u);
+      const uint32_t tf = ((w1 >> (h1 & 31u)) & (w1 >> ((h1 >> 5) & 31u))) | ((w3 >> (h3 & 31u)) & (w3 >> ((h3 >> 5) & 31u))) | (K.bloom5_bits ? 0u : 1u);
       /* (a lane that needs nothing asks for nothing: a gather costs by the line) */
       const bool need = lane < n_items && (tf & 1u) != 0;
       uint32_t pre = 0;
@@ -515,6 +523,42 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           }
         }
       }
+#if ACM_GRAM_PUSH2
+      /* The push of a position's survivors, without a branch and without the scalar unit in its
+       * way: a wave issues one instruction per ~5 cycles whatever its kind, and a scalar
+       * instruction that reads what a vector compare has just written (the ballot -> branch ->
+       * exec mask -> count -> branch tail of round 2, at every position) waits ~35 cycles for it.
+       * Here the queue's fill stays in a vector register (the same value in every lane): slot =
+       * fill + survivors in the lanes below (v_mbcnt seeded with the fill), fill += survivors
+       * (v_bcnt), and the only scalar instructions are the two that narrow the exec mask around
+       * the LDS write -- seven vector instructions after the compare whose mask they read.  The
+       * fill is looked at after every second position (the queue holds 63 + 2 x 64 items). */
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const bool push = __builtin_amdgcn_ubfe (word[j], ix[j], 1u) != 0; /* v_bfe_u32 (it takes the low 5 bits of the offset itself) */
+        const uint64_t m = __ballot (push);
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi ((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo ((uint32_t)m, fill1));
+        asm ("v_bcnt_u32_b32 %0, %1, %0" : "+v"(fill1) : "s"((uint32_t)m));
+        asm ("v_bcnt_u32_b32 %0, %1, %0" : "+v"(fill1) : "s"((uint32_t)(m >> 32)));
+        const uint32_t addr = q1_lds + slot * 8u;
+        const uint64_t item = ((uint64_t)lshl_or (c[8 * h + j + 4], 20u, ix[j]) << 32) | (pos0 + 8 * h + j);
+        uint64_t saved;
+        asm volatile ("s_and_saveexec_b64 %0, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0"
+                      : "=&s"(saved)
+                      : "s"(m), "v"(addr), "v"(item)
+                      : "memory");
+        if (j & 1) {
+          qn1 = uniform (fill1);
+          if (__builtin_expect (qn1 >= WAVE, 0)) {
+            DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)
+            batch_step (WAVE);
+            fill1 = qn1;
+            asm volatile ("" : "+v"(fill1));
+            DIAG (d_cons += __builtin_readcyclecounter () - d_c1; d_b1++;)
+          }
+        }
+      }
+#else
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const bool push = __builtin_amdgcn_ubfe (word[j], ix[j], 1u) != 0; /* v_bfe_u32 (it takes the low 5 bits of the offset itself) */
@@ -530,6 +574,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           }
         }
       }
+#endif
     }
   };
 
@@ -549,6 +594,10 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       c3 = n3;
     }
   }
+#if ACM_GRAM_PUSH2
+  if (!WIDE)
+    qn1 = uniform (fill1);
+#endif
   if (qn1)
     batch_step (qn1);
 #pragma unroll

@@ -1,0 +1,245 @@
+/* dev_order.h -- canonical order of a record set without a global radix sort.
+ * Device code of libac75_amd.so; included by acm_gpu.hip inside its anonymous namespace.
+ *
+ * Canonical order = (end_pos ascending, length descending): what the reference's caller loop emits
+ * (acm_get_match index order, aho_corasick.c:459-466).  The scan leaves records unordered but far
+ * from random: a wave writes the records of one stretch of text side by side.  Round 2 ran a 64-bit
+ * radix sort over everything (eight passes, 3.95 ms each on config 3's 430 M records: 2.9 x the
+ * scan).  Here instead, for records whose positions lie in a known range [pos_lo, pos_lo + span):
+ *   A. bucket = (end_pos - pos_lo) / 4,096.  Histogram: a wave takes 512 consecutive records and
+ *      adds the count of every distinct bucket among them to the global histogram with ONE atomic
+ *      (records that lie side by side fall into few buckets);
+ *   B. exclusive prefix sum of the histogram (hipCUB), then the same walk again: every (piece,
+ *      bucket) pair reserves its run in the bucket with one atomic and the records are copied
+ *      there -- bucket by bucket the records are now in position order, unordered inside;
+ *   C. every bucket is put in order and written to its final place: up to 64 records by one wave
+ *      (rank = number of smaller keys), more by a counting sort over the bucket's positions in LDS
+ *      (a bitonic sort of 4,096-record windows in LDS took 94 us per window: 19 ms on config 3).
+ * Three passes over the records (one of them reads the positions only) instead of eight. */
+constexpr int ORDER_THREADS = 256, ORDER_PER = 8, ORDER_PIECE = ORDER_PER * WAVE; /* records a wave takes at a time */
+
+struct OrderK {
+  const ACMRecord *in;   /* the unordered records */
+  uint64_t n;
+  uint64_t pos_lo;
+  uint32_t wlog;         /* bucket width = 1 << wlog symbols */
+  uint32_t n_buckets;
+  uint32_t len_bits;     /* bits of a length */
+  unsigned int *error;   /* set when a record lies outside [pos_lo, pos_lo + span) */
+};
+
+/* passes A (SCATTER = false: histogram into `hist`) and B (SCATTER = true: `hist` holds the buckets'
+ * cursors, the records go to `out`).  A wave takes ORDER_PIECE = 512 consecutive records, eight per
+ * lane, and goes through the distinct buckets among them: every lane whose record lies in the
+ * bucket at hand is counted by ballot, ONE atomic reserves the run (pass B) or adds the count (pass
+ * A).  Records that lie side by side come from one stretch of text (a wave of the scan kernel wrote
+ * them), so there are a handful of buckets per piece -- and where two stretches meet (the scan
+ * kernel's chunks of 1,024 records: neighbours in the buffer, megabytes apart in the text) it is
+ * two handfuls, nothing worse.  No LDS, no barrier.  (Two earlier forms counted a block's 2,048
+ * records in an LDS array indexed by bucket - lowest bucket: pieces that straddle two chunks fell
+ * out of the array into one global atomic per record -- 27 ms per pass on config 3 -- and an LDS
+ * atomic per record on some ten counters serialised.) */
+template <bool SCATTER>
+__global__ __launch_bounds__ (ORDER_THREADS) void
+order_bucket_kernel (OrderK K, uint32_t *hist, ACMRecord *out) {
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves = (uint64_t)gridDim.x * blockDim.x / WAVE;
+  const uint64_t pieces = (K.n + ORDER_PIECE - 1) / ORDER_PIECE;
+  for (uint64_t piece = wave; piece < pieces; piece += waves) {
+    const uint64_t first = piece * ORDER_PIECE;
+    uint32_t b[ORDER_PER], rk[ORDER_PER];
+    uint4 rec[ORDER_PER];
+    uint64_t todo[ORDER_PER];
+#pragma unroll
+    for (int q = 0; q < ORDER_PER; q++) {
+      const uint64_t i = first + (uint64_t)q * WAVE + lane;
+      b[q] = 0xFFFFFFFFu;
+      rk[q] = 0;
+      if (i < K.n) {
+        uint64_t pos;
+        if (SCATTER) {
+          rec[q] = *reinterpret_cast<const uint4 *> (&K.in[i]);
+          pos = ((uint64_t)rec[q].y << 32) | rec[q].x;
+        } else
+          pos = K.in[i].end_pos;
+        uint64_t bb = (pos - K.pos_lo) >> K.wlog;
+        if (pos < K.pos_lo || bb >= K.n_buckets) { /* outside the range the caller named: kept (in the last bucket), reported */
+          if (K.error)
+            *K.error = 1;
+          bb = K.n_buckets - 1;
+        }
+        b[q] = (uint32_t)bb;
+      }
+      todo[q] = __ballot (b[q] != 0xFFFFFFFFu);
+    }
+    for (;;) {
+      /* the bucket of the first record not yet placed */
+      uint32_t b0 = 0xFFFFFFFFu;
+#pragma unroll
+      for (int q = ORDER_PER - 1; q >= 0; q--)
+        if (todo[q])
+          b0 = __builtin_amdgcn_readlane (b[q], (uint32_t)__builtin_ctzll (todo[q]));
+      if (b0 == 0xFFFFFFFFu)
+        break;
+      uint64_t m[ORDER_PER];
+      uint32_t total = 0;
+#pragma unroll
+      for (int q = 0; q < ORDER_PER; q++) {
+        m[q] = __ballot (b[q] == b0);
+        total += (uint32_t)__popcll (m[q]);
+        todo[q] &= ~m[q];
+      }
+      uint32_t at = 0;
+      if (lane == 0)
+        at = atomicAdd (&hist[b0], total); /* pass B: where this piece's run in the bucket begins */
+      if (SCATTER) {
+        at = __builtin_amdgcn_readfirstlane (at);
+#pragma unroll
+        for (int q = 0; q < ORDER_PER; q++) {
+          if (b[q] == b0)
+            rk[q] = at + rank_below (m[q]);
+          at += (uint32_t)__popcll (m[q]);
+        }
+      }
+    }
+    if (SCATTER) {
+#pragma unroll
+      for (int q = 0; q < ORDER_PER; q++)
+        if (b[q] != 0xFFFFFFFFu)
+          *reinterpret_cast<uint4 *> (&out[rk[q]]) = rec[q];
+    }
+  }
+}
+
+/* pass C.  A bucket covers 1 << wlog <= ORDER_POSITIONS positions; its records lie side by side in
+ * `bucketed`, in no order.
+ * order_small_kernel: buckets of at most 256 records, one wave each, four records per lane -- a
+ * record's place is the number of records of the bucket with a smaller key (position, then longer
+ * before shorter): one v_readlane and four compares per other record, no barrier, no LDS (a block
+ * per bucket with a counting sort in LDS took 24 us per bucket of 200 records: five barriers with
+ * a memory round trip between each).
+ * order_count_kernel: the other buckets, one block each, whatever they hold (the records are
+ * streamed, LDS holds a counter per position): a counting sort by position -- count, exclusive
+ * prefix sums, place -- and then, position by position, the few records that end at the same
+ * symbol put longest first. */
+constexpr uint32_t ORDER_POSITIONS = 4096;
+constexpr int ORDER_COUNT_THREADS = 256;
+
+__device__ __forceinline__ unsigned long long
+order_key (const OrderK &K, uint64_t lo, uint64_t pos, uint32_t length) {
+  const uint64_t lmask = (1ull << K.len_bits) - 1;
+  return ((pos - lo) << K.len_bits) | (lmask - (length & lmask));
+}
+
+constexpr uint32_t ORDER_SMALL = 256; /* records a wave orders by itself: 4 per lane */
+__global__ __launch_bounds__ (256) void
+order_small_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out) {
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves = gridDim.x * blockDim.x / WAVE;
+  constexpr int R = ORDER_SMALL / WAVE;
+  for (uint32_t b = wave; b < K.n_buckets; b += waves) {
+    const uint32_t base = uniform (P[b]), cnt = uniform (P[b + 1]) - base;
+    if (cnt == 0 || cnt > ORDER_SMALL)
+      continue;
+    const uint64_t lo = K.pos_lo + ((uint64_t)b << K.wlog);
+    uint4 rec[R];
+    uint32_t key[R], rank[R]; /* (position in the bucket, length): at most 13 + len_bits bits */
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      rec[r] = make_uint4 (0, 0, 0, 0);
+      key[r] = 0xFFFFFFFFu;
+      rank[r] = 0;
+      const uint32_t i = r * WAVE + lane;
+      if (i < cnt) {
+        rec[r] = *reinterpret_cast<const uint4 *> (&bucketed[base + i]);
+        key[r] = (uint32_t)order_key (K, lo, ((uint64_t)rec[r].y << 32) | rec[r].x, rec[r].z);
+      }
+    }
+    /* a record's place: the number of records of the bucket with a smaller key (keys differ) */
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+      if ((uint32_t)s * WAVE >= cnt)
+        break;
+      const uint32_t upto = cnt - s * WAVE < WAVE ? cnt - s * WAVE : WAVE;
+      for (uint32_t j = 0; j < upto; j++) {
+        const uint32_t kj = __builtin_amdgcn_readlane (key[s], j);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          rank[r] += kj < key[r] ? 1u : 0u;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if ((uint32_t)r * WAVE + lane < cnt)
+        *reinterpret_cast<uint4 *> (&out[base + rank[r]]) = rec[r];
+  }
+}
+
+__global__ __launch_bounds__ (ORDER_COUNT_THREADS) void
+order_count_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *out) {
+  __shared__ uint32_t ctr[ORDER_POSITIONS];
+  __shared__ uint32_t s_part[ORDER_COUNT_THREADS / WAVE];
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  const uint32_t width = 1u << K.wlog; /* <= ORDER_POSITIONS */
+  constexpr uint32_t PER = ORDER_POSITIONS / ORDER_COUNT_THREADS;
+  for (uint32_t b = blockIdx.x; b < K.n_buckets; b += gridDim.x) {
+    const uint32_t base = P[b], cnt = P[b + 1] - base;
+    if (cnt <= ORDER_SMALL)
+      continue;
+    const uint64_t lo = K.pos_lo + ((uint64_t)b << K.wlog);
+    for (uint32_t i = tid; i < ORDER_POSITIONS; i += ORDER_COUNT_THREADS)
+      ctr[i] = 0;
+    __syncthreads ();
+    for (uint32_t i = tid; i < cnt; i += ORDER_COUNT_THREADS)
+      atomicAdd (&ctr[(uint32_t)(bucketed[base + i].end_pos - lo) & (ORDER_POSITIONS - 1)], 1u);
+    __syncthreads ();
+    /* exclusive prefix sums in place: a run of PER counters per thread */
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++)
+      run += ctr[tid * PER + q];
+    const uint32_t incl = wave_incl_scan (run);
+    if (lane == WAVE - 1)
+      s_part[wid] = incl;
+    __syncthreads ();
+    uint32_t acc = incl - run;
+    for (uint32_t w = 0; w < wid; w++)
+      acc += s_part[w];
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) {
+      const uint32_t c = ctr[tid * PER + q];
+      ctr[tid * PER + q] = acc;
+      acc += c;
+    }
+    __syncthreads ();
+    /* place: the counter of a position runs from where its records begin to where they end */
+    for (uint32_t i = tid; i < cnt; i += ORDER_COUNT_THREADS) {
+      const uint4 rec = *reinterpret_cast<const uint4 *> (&bucketed[base + i]);
+      const uint64_t pos = ((uint64_t)rec.y << 32) | rec.x;
+      const uint32_t slot = atomicAdd (&ctr[(uint32_t)(pos - lo) & (ORDER_POSITIONS - 1)], 1u);
+      *reinterpret_cast<uint4 *> (&out[base + slot]) = rec;
+    }
+    /* the block's own stores, then its loads of them (one CU: the L1 all its waves share) */
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+    __syncthreads ();
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+    /* records of one position: longest first (their lengths differ; there are few of them) */
+    for (uint32_t i = tid; i < width; i += ORDER_COUNT_THREADS) {
+      const uint32_t end = ctr[i], begin = i ? ctr[i - 1] : 0u;
+      for (uint32_t a = begin + 1; a < end; a++) { /* insertion sort */
+        const uint4 r = *reinterpret_cast<const uint4 *> (&out[base + a]);
+        uint32_t at = a;
+        while (at > begin) {
+          const uint4 prev = *reinterpret_cast<const uint4 *> (&out[base + at - 1]);
+          if (prev.z >= r.z)
+            break;
+          *reinterpret_cast<uint4 *> (&out[base + at]) = prev;
+          at--;
+        }
+        if (at != a)
+          *reinterpret_cast<uint4 *> (&out[base + at]) = r;
+      }
+    }
+    __syncthreads ();
+  }
+}

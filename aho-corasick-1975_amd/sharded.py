@@ -29,8 +29,15 @@ def gather_records(local, group=None, dst=0):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     out_dev = local.device
+    # ONE code path for both backends: everything below (the all-gather of the counts, the root's
+    # irecv per peer into its slice, the peers' isend) is the same calls whether the group is gloo
+    # or nccl (RCCL); the only difference is this hop -- gloo moves host memory, so CUDA tensors go
+    # through the CPU there (CPU tests, 1-GPU rehearsals) and the result goes back to the device at
+    # the end.  The world-2/3 gloo tests and the two-process gloo test on one GPU therefore execute
+    # every line the 8-GPU nccl run executes, on host tensors; the C caller's multi-GPU entry
+    # (acm_gpu_multi_*, include/acm_gpu.h) does the same gather with hipMemcpyPeerAsync.
     if dist.get_backend(group) == "gloo" and local.is_cuda:
-        local = local.cpu()        # gloo moves host memory only (CPU tests, 1-GPU rehearsals)
+        local = local.cpu()
     dev = local.device
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]

@@ -217,7 +217,7 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
         def e2e():
             plan.scan(text, n_scan, emit_from=halo, pos_base=pos_base, records=records, count=count)
             n = int(count.item())
-            plan.sort(records, n)
+            plan.sort(records, n, pos_base, n_scan)
             return acm.sharded.gather_records(records[:n], dst=0) if world > 1 else records[:n]
 
         gathered = e2e()

@@ -228,6 +228,15 @@ size_t acm_gpu_sort_tmp_bytes (uint64_t n);
 int acm_gpu_sort_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, void *d_tmp,
                                  size_t tmp_bytes, void *stream);
 
+/* The same order for records whose end_pos all lie in [pos_lo, pos_lo + span) -- what a scan of
+ * `span` symbols with pos_base = pos_lo (and any emit_from) leaves: three passes over the records
+ * (position buckets, then sorts of a few thousand records in LDS) instead of the radix sort's
+ * eight.  A record outside the range makes acm_gpu_plan_status report ACM_GPU_E_INTERNAL.
+ * d_tmp must hold acm_gpu_order_tmp_bytes(plan, n, span) bytes.  Asynchronous on `stream`. */
+size_t acm_gpu_order_tmp_bytes (const ACMPlan *plan, uint64_t n, uint64_t span);
+int acm_gpu_order_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, uint64_t pos_lo, uint64_t span,
+                                  void *d_tmp, size_t tmp_bytes, void *stream);
+
 /* Host-buffer convenience: upload, scan, sort, download; blocking.  On ACM_GPU_E_OVERFLOW
  * *n_found holds the capacity needed. */
 int acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint64_t emit_from,
