@@ -50,6 +50,11 @@
     }                                                                                              \
   } while (0)
 
+#ifdef ACM_GRAM_NT_BOTH /* experiment builds (make expd D=...): non-temporal text loads and record stores in the 4-gram kernel */
+#define ACM_GRAM_NT_TEXT
+#define ACM_GRAM_NT_REC
+#endif
+
 /* Diagnostic build only (-DACM_DIAG, libac75_amd_diag.so, used by tools/diag_*.py): eight per-wave
  * counters (cycle stamps, call counts) whose meaning each kernel defines where it writes them.
  * Nothing of this exists in the product build. */
@@ -2461,8 +2466,20 @@ acm_gpu_sort_tmp_bytes (uint64_t n) {
   return align256 (n * 8) * 2 + align256 (n * 16) + align256 (cub_sort_bytes (n)) + 256;
 }
 
+namespace {
+int radix_sort_records (ACMPlan *plan, ACMRecord *d_records, uint64_t n, void *d_tmp, size_t tmp_bytes, void *stream, uint64_t pos_lo, int key_bits);
+}
+
 extern "C" int
 acm_gpu_sort_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, void *d_tmp, size_t tmp_bytes, void *stream) {
+  return radix_sort_records (plan, d_records, n, d_tmp, tmp_bytes, stream, 0, 64);
+}
+
+namespace {
+/* key = (end_pos - pos_lo) << len_bits | (max - length); only the low key_bits bits are sorted on
+ * (a caller that knows the range of the positions saves the radix passes over bits that are zero) */
+int
+radix_sort_records (ACMPlan *plan, ACMRecord *d_records, uint64_t n, void *d_tmp, size_t tmp_bytes, void *stream, uint64_t pos_lo, int key_bits) {
   if (!plan || (n && (!d_records || !d_tmp)))
     return ACM_GPU_E_ARG;
   if (n <= 1)
@@ -2481,20 +2498,22 @@ acm_gpu_sort_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, vo
   while ((1u << len_bits) <= plan->finfo.lmax)
     len_bits++;
   /* key = end_pos in the high bits, (max - length) below: 64 - len_bits bits remain for positions */
-  hipLaunchKernelGGL (make_keys_kernel, dim3 ((uint32_t)((n + 255) / 256)), dim3 (256), 0, st, d_records, n, len_bits, k0);
+  hipLaunchKernelGGL (make_keys_kernel, dim3 ((uint32_t)((n + 255) / 256)), dim3 (256), 0, st, d_records, n, len_bits, pos_lo, k0);
   HIP_TRY (hipGetLastError ());
   hipcub::DoubleBuffer<uint64_t> keys (k0, k1);
   hipcub::DoubleBuffer<Rec16> vals (reinterpret_cast<Rec16 *> (d_records), v1);
-  HIP_TRY (hipcub::DeviceRadixSort::SortPairs (cub_tmp, cub_bytes, keys, vals, (int)n, 0, 64, st));
+  HIP_TRY (hipcub::DeviceRadixSort::SortPairs (cub_tmp, cub_bytes, keys, vals, (int)n, 0, key_bits, st));
   if (vals.Current () != reinterpret_cast<Rec16 *> (d_records))
     HIP_TRY (hipMemcpyAsync (d_records, vals.Current (), n * 16, hipMemcpyDeviceToDevice, st));
   return ACM_GPU_OK;
 }
+} // namespace
 
 /* ---- canonical order of records whose positions lie in [pos_lo, pos_lo + span): dev_order.h */
 namespace {
 struct OrderPlan {
-  uint32_t wlog = 0, n_buckets = 0, len_bits = 1;
+  uint32_t wlog = 0, n_buckets = 0, len_bits = 1, key_bits = 64;
+  bool sparse = false; /* fewer than 8 records per 4,096 positions: pass C goes by windows of buckets, not by bucket */
   size_t o_hist = 0, o_cur = 0, o_rec = 0, o_cub = 0, cub_bytes = 0, total = 0;
   bool ok = false;
 };
@@ -2503,22 +2522,25 @@ order_layout (const ACMPlan *plan, uint64_t n, uint64_t span) {
   OrderPlan L;
   if (n == 0 || span == 0 || n >= (1ull << 31))
     return L;
-  /* buckets of ORDER_POSITIONS positions (fewer when the whole range is shorter) */
-  uint32_t wlog = 0;
-  while ((2u << wlog) <= ORDER_POSITIONS && (1ull << wlog) < span)
-    wlog++;
-  const uint64_t nb = (span >> wlog) + 1;
   uint32_t span_bits = 1, len_bits = 1;
   while ((1ull << span_bits) < span && span_bits < 63)
     span_bits++;
   const uint32_t lmax = plan->finfo.lmax > (plan->delta ? plan->delta->finfo.lmax : 0) ? plan->finfo.lmax : (plan->delta ? plan->delta->finfo.lmax : 0);
   while ((1u << len_bits) <= lmax)
     len_bits++;
+  L.len_bits = len_bits;
+  L.key_bits = span_bits + len_bits < 64 ? (int)(span_bits + len_bits) : 64;
+  /* buckets of ORDER_POSITIONS positions (fewer when the whole range is shorter): whatever a
+   * bucket holds, order_count_kernel has a counter per position for it */
+  uint32_t wlog = 0;
+  while ((2u << wlog) <= ORDER_POSITIONS && (1ull << wlog) < span)
+    wlog++;
+  L.sparse = (double)n * 4096.0 < 8.0 * (double)span;
+  const uint64_t nb = (span >> wlog) + 1;
   if (nb >= (1ull << 28) || span_bits + len_bits > 63 || wlog + len_bits > 31) /* (a bucket's keys are 32-bit) */
     return L;
   L.wlog = wlog;
   L.n_buckets = (uint32_t)nb;
-  L.len_bits = len_bits;
   size_t cub = 0;
   (void)hipcub::DeviceScan::ExclusiveSum (nullptr, cub, static_cast<uint32_t *> (nullptr), static_cast<uint32_t *> (nullptr), (int)(nb + 1), nullptr);
   L.cub_bytes = cub;
@@ -2554,7 +2576,7 @@ acm_gpu_order_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, u
   const OrderPlan L = order_layout (plan, n, span);
   const char *env = getenv ("ACM_GPU_ORDER"); /* radix: always the radix sort (experiments, tests) */
   if (!L.ok || (env && strcmp (env, "radix") == 0))
-    return acm_gpu_sort_records_device (plan, d_records, n, d_tmp, tmp_bytes, stream);
+    return radix_sort_records (plan, d_records, n, d_tmp, tmp_bytes, stream, pos_lo, L.key_bits);
   HIP_TRY (hipSetDevice (plan->device));
   hipStream_t st = static_cast<hipStream_t> (stream);
   unsigned char *t = static_cast<unsigned char *> (d_tmp);
@@ -2579,10 +2601,18 @@ acm_gpu_order_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, u
   HIP_TRY (hipMemcpyAsync (hist, cur, ((size_t)L.n_buckets + 1) * 4, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL (order_bucket_kernel<true>, dim3 (grid), dim3 (ORDER_THREADS), 0, st, K, hist, bucketed);
   HIP_TRY (hipGetLastError ());
-  /* pass C: small buckets by a wave each, the others by a block each (each kernel skips the other's) */
-  const uint32_t sgrid = (uint32_t)((L.n_buckets + 3) / 4 < (uint32_t)plan->cu_count * 16 ? (L.n_buckets + 3) / 4 : (uint32_t)plan->cu_count * 16);
-  hipLaunchKernelGGL (order_small_kernel, dim3 (sgrid), dim3 (256), 0, st, K, cur, bucketed, d_records);
-  const uint32_t cgrid = (uint32_t)(L.n_buckets < (uint32_t)plan->cu_count * 8 ? L.n_buckets : (uint32_t)plan->cu_count * 8);
+  /* pass C: buckets (dense record sets) or windows of buckets (sparse ones) of up to 256 records by
+   * a wave each, crowded buckets by a block each (each kernel skips the other's) */
+  if (L.sparse) {
+    const uint64_t windows = (n + ORDER_WINDOW - 1) / ORDER_WINDOW, wblocks = (windows + 3) / 4;
+    const uint32_t wgrid = (uint32_t)(wblocks < (uint64_t)plan->cu_count * 16 ? wblocks : (uint64_t)plan->cu_count * 16);
+    hipLaunchKernelGGL (order_window_kernel, dim3 (wgrid), dim3 (256), 0, st, K, cur, bucketed, d_records);
+  } else {
+    const uint32_t sgrid = (uint32_t)((L.n_buckets + 3) / 4 < (uint32_t)plan->cu_count * 16 ? (L.n_buckets + 3) / 4 : (uint32_t)plan->cu_count * 16);
+    hipLaunchKernelGGL (order_small_kernel, dim3 (sgrid), dim3 (256), 0, st, K, cur, bucketed, d_records);
+  }
+  const uint32_t cblocks = (L.n_buckets + ORDER_COUNT_THREADS - 1) / ORDER_COUNT_THREADS;
+  const uint32_t cgrid = cblocks < (uint32_t)plan->cu_count * 8 ? cblocks : (uint32_t)plan->cu_count * 8;
   hipLaunchKernelGGL (order_count_kernel, dim3 (cgrid), dim3 (ORDER_COUNT_THREADS), 0, st, K, cur, bucketed, d_records);
   HIP_TRY (hipGetLastError ());
   return ACM_GPU_OK;

@@ -205,7 +205,13 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
 
   auto load_group = [&] (uint32_t g) -> uint4 {
     const uint32_t blk = g * WAVE + lane;
+#ifdef ACM_GRAM_NT_TEXT /* experiment: the text as a stream that should not push the second stage's tables out of L2 */
+    typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+    const u32x4 v = __builtin_nontemporal_load (reinterpret_cast<const u32x4 *> (text16) + (blk < last_blk ? blk : last_blk));
+    return make_uint4 (v.x, v.y, v.z, v.w);
+#else
     return text16[blk < last_blk ? blk : last_blk];
+#endif
   };
   auto walk_batch = [&] (uint32_t n_items) {
     DIAG (const unsigned long long d_c0 = __builtin_readcyclecounter ();)

@@ -122,11 +122,11 @@ patch_kernel (PatchTables T, const uint4 *__restrict__ patches, uint32_t n) {
 
 /* ------------------------------------------------------------------ sort keys */
 __global__ void
-make_keys_kernel (const ACMRecord *rec, uint64_t n, uint32_t len_bits, uint64_t *keys) {
+make_keys_kernel (const ACMRecord *rec, uint64_t n, uint32_t len_bits, uint64_t pos_lo, uint64_t *keys) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const uint64_t lmask = (1ull << len_bits) - 1;
-    keys[i] = (rec[i].end_pos << len_bits) | (lmask - (rec[i].length & lmask));
+    keys[i] = ((rec[i].end_pos - pos_lo) << len_bits) | (lmask - (rec[i].length & lmask));
   }
 }
 

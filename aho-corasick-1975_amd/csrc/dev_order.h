@@ -17,6 +17,7 @@
  *      (a bitonic sort of 4,096-record windows in LDS took 94 us per window: 19 ms on config 3).
  * Three passes over the records (one of them reads the positions only) instead of eight. */
 constexpr int ORDER_THREADS = 256, ORDER_PER = 8, ORDER_PIECE = ORDER_PER * WAVE; /* records a wave takes at a time */
+constexpr int ORDER_ROUNDS = 12; /* distinct buckets of a piece taken one at a time before the rest goes lane by lane */
 
 struct OrderK {
   const ACMRecord *in;   /* the unordered records */
@@ -72,7 +73,11 @@ order_bucket_kernel (OrderK K, uint32_t *hist, ACMRecord *out) {
       }
       todo[q] = __ballot (b[q] != 0xFFFFFFFFu);
     }
-    for (;;) {
+    /* up to ORDER_ROUNDS distinct buckets are taken one at a time (all their records in the piece
+     * counted by ballot, one atomic each); a piece whose records are spread wider than that --
+     * sparse matches: config 2 has two records per bucket -- hands the rest over lane by lane,
+     * every lane its own atomic, all of them in flight together */
+    for (int round = 0; round < ORDER_ROUNDS; round++) {
       /* the bucket of the first record not yet placed */
       uint32_t b0 = 0xFFFFFFFFu;
 #pragma unroll
@@ -102,6 +107,13 @@ order_bucket_kernel (OrderK K, uint32_t *hist, ACMRecord *out) {
         }
       }
     }
+#pragma unroll
+    for (int q = 0; q < ORDER_PER; q++)
+      if ((todo[q] >> lane) & 1ull) {
+        const uint32_t at = atomicAdd (&hist[b[q]], 1u);
+        if (SCATTER)
+          rk[q] = at;
+      }
     if (SCATTER) {
 #pragma unroll
       for (int q = 0; q < ORDER_PER; q++)
@@ -132,46 +144,104 @@ order_key (const OrderK &K, uint64_t lo, uint64_t pos, uint32_t length) {
 }
 
 constexpr uint32_t ORDER_SMALL = 256; /* records a wave orders by itself: 4 per lane */
+
+/* the wave puts the cnt <= 256 records bucketed[base ...] in order into out[base ...]: a record's
+ * place is the number of records with a smaller key (position from `lo` on, then longer before
+ * shorter; keys differ).  KEY = uint32_t when the positions span at most a bucket. */
+template <typename KEY>
+__device__ __forceinline__ void
+order_wave_sort (const OrderK &K, uint64_t lo, uint32_t base, uint32_t cnt, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out,
+                 uint32_t lane) {
+  constexpr int R = ORDER_SMALL / WAVE;
+  uint4 rec[R];
+  KEY key[R];
+  uint32_t rank[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    rec[r] = make_uint4 (0, 0, 0, 0);
+    key[r] = ~(KEY)0;
+    rank[r] = 0;
+    const uint32_t i = r * WAVE + lane;
+    if (i < cnt) {
+      rec[r] = *reinterpret_cast<const uint4 *> (&bucketed[base + i]);
+      key[r] = (KEY)order_key (K, lo, ((uint64_t)rec[r].y << 32) | rec[r].x, rec[r].z);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < R; s++) {
+    if ((uint32_t)s * WAVE >= cnt)
+      break;
+    const uint32_t upto = cnt - s * WAVE < WAVE ? cnt - s * WAVE : WAVE;
+    for (uint32_t j = 0; j < upto; j++) {
+      KEY kj;
+      if (sizeof (KEY) == 8)
+        kj = (KEY)(((unsigned long long)__builtin_amdgcn_readlane ((uint32_t)((unsigned long long)key[s] >> 32), j) << 32) |
+                   __builtin_amdgcn_readlane ((uint32_t)key[s], j));
+      else
+        kj = (KEY)__builtin_amdgcn_readlane ((uint32_t)key[s], j);
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        rank[r] += kj < key[r] ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if ((uint32_t)r * WAVE + lane < cnt)
+      *reinterpret_cast<uint4 *> (&out[base + rank[r]]) = rec[r];
+}
+
+/* dense record sets: a wave per bucket of up to 256 records */
 __global__ __launch_bounds__ (256) void
 order_small_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out) {
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves = gridDim.x * blockDim.x / WAVE;
-  constexpr int R = ORDER_SMALL / WAVE;
   for (uint32_t b = wave; b < K.n_buckets; b += waves) {
     const uint32_t base = uniform (P[b]), cnt = uniform (P[b + 1]) - base;
     if (cnt == 0 || cnt > ORDER_SMALL)
       continue;
-    const uint64_t lo = K.pos_lo + ((uint64_t)b << K.wlog);
-    uint4 rec[R];
-    uint32_t key[R], rank[R]; /* (position in the bucket, length): at most 13 + len_bits bits */
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      rec[r] = make_uint4 (0, 0, 0, 0);
-      key[r] = 0xFFFFFFFFu;
-      rank[r] = 0;
-      const uint32_t i = r * WAVE + lane;
-      if (i < cnt) {
-        rec[r] = *reinterpret_cast<const uint4 *> (&bucketed[base + i]);
-        key[r] = (uint32_t)order_key (K, lo, ((uint64_t)rec[r].y << 32) | rec[r].x, rec[r].z);
-      }
+    order_wave_sort<uint32_t> (K, K.pos_lo + ((uint64_t)b << K.wlog), base, cnt, bucketed, out, lane);
+  }
+}
+
+/* sparse record sets (most buckets hold a record or two): a wave per WINDOW of whole buckets --
+ * from the first bucket that begins at or after record 128 k to the first that begins at or after
+ * record 128 (k + 1) -- ordered in one go when it holds at most 256 records; else (a crowded
+ * bucket among sparse ones: the start of config 2's text has one of 934) its buckets one by one,
+ * those of more than 256 left to order_count_kernel. */
+constexpr uint32_t ORDER_WINDOW = 128;
+__device__ __forceinline__ uint32_t
+order_first_bucket_at (const uint32_t *__restrict__ P, uint32_t n_buckets, uint64_t want) {
+  uint32_t lo = 0, hi = n_buckets;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (uniform (P[mid]) < want)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+__global__ __launch_bounds__ (256) void
+order_window_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out) {
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves = (uint64_t)gridDim.x * blockDim.x / WAVE;
+  const uint64_t windows = (K.n + ORDER_WINDOW - 1) / ORDER_WINDOW;
+  for (uint64_t k = wave; k < windows; k += waves) {
+    const uint32_t b0 = order_first_bucket_at (P, K.n_buckets, k * ORDER_WINDOW), b1 = order_first_bucket_at (P, K.n_buckets, (k + 1) * ORDER_WINDOW);
+    if (b1 <= b0)
+      continue;
+    const uint32_t base = uniform (P[b0]), cnt = uniform (P[b1]) - base;
+    if (cnt == 0)
+      continue;
+    if (cnt <= ORDER_SMALL) {
+      order_wave_sort<unsigned long long> (K, K.pos_lo + ((uint64_t)b0 << K.wlog), base, cnt, bucketed, out, lane);
+      continue;
     }
-    /* a record's place: the number of records of the bucket with a smaller key (keys differ) */
-#pragma unroll
-    for (int s = 0; s < R; s++) {
-      if ((uint32_t)s * WAVE >= cnt)
-        break;
-      const uint32_t upto = cnt - s * WAVE < WAVE ? cnt - s * WAVE : WAVE;
-      for (uint32_t j = 0; j < upto; j++) {
-        const uint32_t kj = __builtin_amdgcn_readlane (key[s], j);
-#pragma unroll
-        for (int r = 0; r < R; r++)
-          rank[r] += kj < key[r] ? 1u : 0u;
-      }
+    for (uint32_t b = b0; b < b1; b++) {
+      const uint32_t bb = uniform (P[b]), bc = uniform (P[b + 1]) - bb;
+      if (bc && bc <= ORDER_SMALL)
+        order_wave_sort<uint32_t> (K, K.pos_lo + ((uint64_t)b << K.wlog), bb, bc, bucketed, out, lane);
     }
-#pragma unroll
-    for (int r = 0; r < R; r++)
-      if ((uint32_t)r * WAVE + lane < cnt)
-        *reinterpret_cast<uint4 *> (&out[base + rank[r]]) = rec[r];
   }
 }
 
@@ -182,10 +252,21 @@ order_count_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *_
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   const uint32_t width = 1u << K.wlog; /* <= ORDER_POSITIONS */
   constexpr uint32_t PER = ORDER_POSITIONS / ORDER_COUNT_THREADS;
-  for (uint32_t b = blockIdx.x; b < K.n_buckets; b += gridDim.x) {
+  /* a block looks at ORDER_COUNT_THREADS buckets at a time (a thread each) and then takes the
+   * crowded ones among them one by one: where there are none -- most of the time -- that is all */
+  __shared__ uint32_t s_list[ORDER_COUNT_THREADS];
+  __shared__ uint32_t s_nlist;
+  for (uint32_t first = blockIdx.x * ORDER_COUNT_THREADS; first < K.n_buckets; first += gridDim.x * ORDER_COUNT_THREADS) {
+    if (tid == 0)
+      s_nlist = 0;
+    __syncthreads ();
+    if (first + tid < K.n_buckets && P[first + tid + 1] - P[first + tid] > ORDER_SMALL)
+      s_list[atomicAdd (&s_nlist, 1u)] = first + tid;
+    __syncthreads ();
+    const uint32_t nlist = s_nlist;
+  for (uint32_t li = 0; li < nlist; li++) {
+    const uint32_t b = s_list[li];
     const uint32_t base = P[b], cnt = P[b + 1] - base;
-    if (cnt <= ORDER_SMALL)
-      continue;
     const uint64_t lo = K.pos_lo + ((uint64_t)b << K.wlog);
     for (uint32_t i = tid; i < ORDER_POSITIONS; i += ORDER_COUNT_THREADS)
       ctr[i] = 0;
@@ -242,4 +323,7 @@ order_count_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *_
     }
     __syncthreads ();
   }
+    __syncthreads ();
+  }
 }
+

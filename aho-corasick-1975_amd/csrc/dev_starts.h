@@ -438,7 +438,13 @@ emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t kw, uint32_t le
         if (hit) {
           const uint64_t gp = E.pos_base + p;
           const uint32_t off = (hn + rank_below (m)) << 4;
+#ifdef ACM_GRAM_NT_REC /* experiment: the records as a stream that should not occupy L2 */
+          typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+          u32x4 v = { (uint32_t)gp, (uint32_t)(gp >> 32), length, kw };
+          __builtin_nontemporal_store (v, reinterpret_cast<u32x4 *> (reinterpret_cast<unsigned char *> (here.dst) + off));
+#else
           *reinterpret_cast<uint4 *> (reinterpret_cast<unsigned char *> (here.dst) + off) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), length, kw);
+#endif
         }
         tally = hn + total;
       } else {

@@ -277,6 +277,54 @@ def test_overflow_is_reported_not_silent(torch_cuda):
     assert np.array_equal(plan.scan_sorted(_dev(torch_cuda, text)), o.scan(text))
 
 
+@pytest.mark.parametrize("shape", ["dense", "sparse", "crowded_in_sparse", "one_position", "tiny"])
+def test_order_records_by_buckets_equals_a_plain_sort(torch_cuda, shape):
+    """acm_gpu_order_records_device (position buckets, wave sorts, counting sorts) on record sets it
+    has to get right whatever a scan leaves: dense (every bucket a counting or wave sort), sparse
+    (windows of buckets), a crowded stretch inside a sparse set, many records at ONE position
+    (longest first), a handful.  Against numpy's sort of the same records; the radix fallback
+    (ACM_GPU_ORDER=radix is read per call) must give the same."""
+    torch = torch_cuda
+    rng = np.random.default_rng(sum(map(ord, shape)))
+    m, _ = build_pair([b"a" * k for k in range(1, 13)], 1)      # lmax 12: lengths 1..12 are valid
+    plan = m.plan(0)
+    pos_lo, span = 1 << 33, 1 << 24
+    if shape == "dense":
+        pos = rng.integers(0, span, size=300000)
+    elif shape == "sparse":
+        pos = rng.integers(0, span, size=3000)
+    elif shape == "crowded_in_sparse":
+        pos = np.concatenate([rng.integers(0, span, size=2000), rng.integers(5 << 12, (5 << 12) + 3000, size=1500),
+                              rng.integers(span - 700, span, size=900)])
+    elif shape == "one_position":
+        pos = np.concatenate([np.full(12, 777), rng.integers(0, span, size=40), np.full(12, span - 1)])
+    else:
+        pos = np.array([5, 3, 5, 9, 0])
+    # distinct (position, length) pairs: a keyword is its end and its length
+    pairs = np.unique(np.stack([pos, rng.integers(1, 13, size=pos.size)], axis=1), axis=0)
+    if shape == "one_position":
+        pairs = np.unique(np.concatenate([pairs, np.stack([np.full(12, 777), np.arange(1, 13)], axis=1),
+                                          np.stack([np.full(12, span - 1), np.arange(1, 13)], axis=1)]), axis=0)
+    rng.shuffle(pairs)
+    n = pairs.shape[0]
+    rec = np.zeros(n, dtype=acm.RECORD_DTYPE)
+    rec["end_pos"] = pairs[:, 0] + pos_lo
+    rec["length"] = pairs[:, 1]
+    rec["keyword_id"] = rng.integers(0, 1 << 30, size=n)
+    want = rec[np.lexsort((-rec["length"].astype(np.int64), rec["end_pos"]))]
+    for mode in ("buckets", "radix"):
+        if mode == "radix":
+            os.environ["ACM_GPU_ORDER"] = "radix"
+        try:
+            dev = torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.int64).reshape(n, 2).copy()).cuda()
+            plan.sort(dev, n, pos_lo, span)
+            got = np.frombuffer(dev.cpu().numpy().tobytes(), dtype=acm.RECORD_DTYPE)
+        finally:
+            os.environ.pop("ACM_GPU_ORDER", None)
+        assert np.array_equal(got, want), (shape, mode)
+    plan.status()
+
+
 def test_dense_matches_everywhere(torch_cuda):
     """Output blow-up: nested keywords matching at every position (queue flush path)."""
     kws = [b"a" * k for k in range(1, 9)] + [b"ab", b"b"]
