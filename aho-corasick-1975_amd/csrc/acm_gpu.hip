@@ -1041,6 +1041,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
       p->GK.g5peek = u32p (o_g5peek);
       p->GK.peek_packed = peek_packed ? 1u : 0u;
       p->GK.d5_begin = fv.depth_start[5 <= fi.lmax + 1 ? 5 : fi.lmax + 1];
+      p->GK.d5_rel = peek_packed ? 1u : 0u; /* (fewer than 2^23 states in all: a record index leaves bits 24-29 free too) */
       p->GK.bloom_off = bloom_off;
       p->GK.bloomT_bits = bloomT_bits;
       p->GK.bloom5_bits = bloom5_bits;

@@ -195,6 +195,10 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
 
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint32_t wib = uniform (threadIdx.x / WAVE);
+#ifdef ACM_DENSE_PRIO /* experiment (MI355X_MICROARCH.md, two waves per SIMD, item 4): static priority for the younger half of the block */
+  if (wib >= (DENSE_THREADS / WAVE) / 2)
+    __builtin_amdgcn_s_setprio (1);
+#endif
   uint2 *queue = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * QCAP;
   const uint32_t waves_per_block = blockDim.x / WAVE;
   const uint32_t wave = blockIdx.x * waves_per_block + wib;

@@ -73,6 +73,7 @@ struct GramK {
    * before any record: 708 KB that stay in L2 */
   const uint32_t *g5peek; /* 4 bytes per state when peek_packed (record | symbol << 23 | GRAM_NO_PEEK's bit 31), else 8 */
   uint32_t d5_begin, peek_packed;
+  uint32_t d5_rel;        /* fewer than 2^24 depth-5 states: walk items name them by index and carry the 6th symbol's class */
   uint32_t R;             /* groups per tile */
   uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
 };
@@ -115,6 +116,16 @@ mad_u24 (uint32_t a, uint32_t b, uint32_t c) { /* (the compiler turns the C expr
   return r;
 }
 constexpr uint32_t WT_TERM = 0x80000000u, WT_KIDS = 0x40000000u;
+/* first-queue item of the narrow kernel, second word: 4-gram index (20 bits) | class of the 5th
+ * symbol << 20 | class of the 6th << 25, GRAM_CLS_UNKNOWN where it is not at hand (a lane holds the
+ * classes of its 16 symbols and of the next 4: the 6th symbol of its last position is beyond them;
+ * classes are below 30) */
+constexpr uint32_t GRAM_CLS_UNKNOWN = 31;
+__device__ __forceinline__ uint32_t
+gram_item_word (const uint32_t (&c)[20], int j, uint32_t idx) {
+  const uint32_t y = lshl_or (c[j + 4], 20u, idx);
+  return lshl_or (j + 5 < 20 ? c[j + 5] : GRAM_CLS_UNKNOWN, 25u, y);
+}
 
 template <bool COUNT_ONLY, bool SHORTS, bool WIDE>
 __global__ __launch_bounds__ (SPARSE_THREADS) void
@@ -149,6 +160,9 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     Kc.remap_base = WIDE ? K.d4_begin : K.d5_begin;
     Kc.peek = K.g5peek;
     Kc.peek_packed = K.peek_packed;
+    Kc.peek_rel = K.d5_rel;
+    Kc.lo = K.lo;
+    Kc.span = K.span;
     *Ks = Kc;
     *Es = E;
   }
@@ -228,6 +242,12 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   bool st_term = false;
   uint32_t st_pos = 0, st_what = 0;
   auto consume_terminal = [&] () {
+#if defined(ACM_GRAM_ABLATE) && ACM_GRAM_ABLATE == 3 /* experiment: the records are gathered and only looked at */
+    st_term = false;
+    if (pend_n[0])
+      asm volatile ("" :: "v"(pend_rx[0]), "v"(pend_rw[0]));
+    return;
+#endif
     if (pend_n[0]) {
       if (WIDE) {
         /* the slot that came back is the first of the probe sequence: a hit, an empty slot (the
@@ -262,8 +282,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     st_term = false;
   };
   auto consume_pass = [&] () {
+#if defined(ACM_GRAM_ABLATE) && ACM_GRAM_ABLATE == 3
+    return;
+#endif
     if (pend_n[0]) {
-      const uint32_t c4 = pend_item[0].y >> 20;
+      const uint32_t c4 = WIDE ? 0u : (pend_item[0].y >> 20) & 31u;
       const bool pass = lane < pend_n[0] && ((pend_rx[0] >> (WIDE ? 0u : c4)) & 1u);
       const uint64_t m = __ballot (pass);
       if (m) {
@@ -274,10 +297,20 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
         if (pass) {
           if (WIDE)
             q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 3, pend_ry[0] | WI_REPORTED);
-          else /* the depth-5 state, at the 5th symbol */
-            q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 4, pend_rz[0] + __popc (pend_rx[0] & ((1u << c4) - 1u)));
+          else { /* the depth-5 state, at the 5th symbol */
+            const uint32_t st5 = pend_rz[0] + __popc (pend_rx[0] & ((1u << c4) - 1u));
+            /* (with the class of the 6th symbol when the first queue's item brought it: the walk's
+             * first look at a candidate -- its peek entry against the next symbol, where 25 of 26
+             * end -- then needs no text: re-reading a byte of text that has long left L2 was a
+             * 128-byte line from the Infinity Cache per candidate, 2 to 3 GB per 2 GiB launch) */
+            q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 4, K.d5_rel ? (st5 - K.d5_begin) | ((pend_item[0].y >> 25) & 31u) << 24 : st5);
+          }
         }
         qn2 = uniform (qn2 + (uint32_t)__popcll (m));
+#if defined(ACM_GRAM_ABLATE) && ACM_GRAM_ABLATE == 4 /* experiment: the walk candidates are queued and dropped */
+        if (qn2 >= WAVE)
+          qn2 -= WAVE;
+#endif
         while (qn2 >= WAVE)
           walk_batch (WAVE);
       }
@@ -336,8 +369,12 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       pend_item[GRAM_DEPTH - 1] = it;
       pend_w2 = K.wtab[(it.y * WIDE_H2) >> (32 - K.wtab_log2)];
     } else {
+#if defined(ACM_GRAM_ABLATE) && ACM_GRAM_ABLATE == 1 /* experiment: the items are taken off the queue and dropped */
+      asm volatile ("" :: "v"(it.x), "v"(it.y));
+      return;
+#endif
       consume_terminal ();
-      const uint32_t idx = it.y & 0xFFFFFu, c5 = it.y >> 20;
+      const uint32_t idx = it.y & 0xFFFFFu, c5 = (it.y >> 20) & 31u;
       /* the words of the two filters (word scale and byte offset: wave-uniform, in SGPRs; without
        * filters scale 0 reads some word and the answer is ignored -- no branch here: a value
        * loaded under one must be looked at before its block ends) and of the 4-gram bits */
@@ -357,7 +394,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       pend_item[GRAM_DEPTH - 1] = it;
       const uint32_t tf = ((w1 >> (h1 & 31u)) & (w1 >> ((h1 >> 5) & 31u))) | ((w3 >> (h3 & 31u)) & (w3 >> ((h3 >> 5) & 31u))) | (K.bloom5_bits ? 0u : 1u);
       /* (a lane that needs nothing asks for nothing: a gather costs by the line) */
+#if defined(ACM_GRAM_ABLATE) && ACM_GRAM_ABLATE == 2 /* experiment: the filters are asked, nothing is gathered */
+      const bool need = lane < n_items && (tf & 1u) != 0 && w1 == 0x12345u;
+#else
       const bool need = lane < n_items && (tf & 1u) != 0;
+#endif
       uint32_t pre = 0;
       if (need)
         pre = K.g4prefix[idx >> 5];
@@ -547,7 +588,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
         asm ("v_bcnt_u32_b32 %0, %1, %0" : "+v"(fill1) : "s"((uint32_t)m));
         asm ("v_bcnt_u32_b32 %0, %1, %0" : "+v"(fill1) : "s"((uint32_t)(m >> 32)));
         const uint32_t addr = q1_lds + slot * 8u;
-        const uint64_t item = ((uint64_t)lshl_or (c[8 * h + j + 4], 20u, ix[j]) << 32) | (pos0 + 8 * h + j);
+        const uint64_t item = ((uint64_t)gram_item_word (c, 8 * h + j, ix[j]) << 32) | (pos0 + 8 * h + j);
         uint64_t saved;
         asm volatile ("s_and_saveexec_b64 %0, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0"
                       : "=&s"(saved)
@@ -571,7 +612,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
         const uint64_t m = __ballot (push);
         if (m) {
           if (push)
-            q1[qn1 + rank_below (m)] = make_uint2 (pos0 + 8 * h + j, lshl_or (c[8 * h + j + 4], 20u, ix[j]));
+            q1[qn1 + rank_below (m)] = make_uint2 (pos0 + 8 * h + j, gram_item_word (c, 8 * h + j, ix[j]));
           qn1 = uniform (qn1 + (uint32_t)__popcll (m));
           if (__builtin_expect (qn1 >= WAVE, 0)) {
             DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)

@@ -41,6 +41,9 @@ struct StartsK {
    * GRAM_NO_PEEK} */
   const uint32_t *peek;
   uint32_t peek_packed; /* 4 bytes per state: record | symbol << 23 | "look at the record" << 31; else {record, symbol or GRAM_NO_PEEK} */
+  /* walk_starts<.., 2>: a fresh item's second word is (depth-5 state - remap_base) | class of the
+   * symbol after its position << 24 (31: not known), and [lo, lo + span) is the alphabet */
+  uint32_t peek_rel, lo, span;
 };
 constexpr uint32_t ST_ALWAYS = 0x80000000u, ST_SECOND = 0x40000000u, ST_STATE = 0x3FFFFFFFu;
 
@@ -490,6 +493,14 @@ walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue
   const uint2 it = alive ? queue[base + lane] : make_uint2 (0, 0);
   const uint32_t p = it.x;
   uint32_t st = it.y & ST_STATE;
+  /* GRAM == 2 with peek_rel: bits 24-28 of an item's second word hold the class of the symbol
+   * after its position, or 31 for "not known" -- a fresh item (bits 0-23: depth-5 state -
+   * remap_base) got it from the first queue, the record item it turns into at the same position
+   * (bits 0-22: the record) keeps it: the two looks most candidates get need no text */
+  const bool with_cls = GRAM == 2 && K.peek_rel && alive;
+  const uint32_t next_cls = with_cls ? (it.y >> 24) & 31u : 31u;
+  if (with_cls)
+    st = (it.y & WI_RECORD) ? it.y & 0x7FFFFFu : (it.y & 0xFFFFFFu) + K.remap_base;
   /* GRAM == 2: a fresh item (a depth-5 state by its id) asks the peek table first and comes back
    * as a record item at the same position if the next symbol can go on (or the state's record has
    * to be seen anyway); only record items touch the records */
@@ -511,7 +522,11 @@ walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue
     rb = K.srec[2 * st + 1];
   }
   const bool more = alive && p + 1 < E.n;
-  const uint32_t c1 = more ? (uint32_t)text[p + 1] : 0u;
+  uint32_t c1 = 0;
+  if (next_cls != 31u) /* the symbol itself, or no symbol of the alphabet: no text is read */
+    c1 = next_cls < K.span ? K.lo + next_cls : 0x100u;
+  else if (more)
+    c1 = (uint32_t)text[p + 1];
   /* (4-gram kernels: word 1 of a record is n_edges | depth << 16, word 3 the keyword id + 1 of a
    * terminal state -- what a record written on the spot needs; fill_gram_tables) */
   emit_terminals<COUNT_ONLY, GRAM == 2> (E, regular && !(it.y & WI_REPORTED) && ra.w != 0 && p >= E.emit_from, p,
@@ -543,7 +558,8 @@ walk_starts (const StartsK *Kp, const EmitCtx *Ep, const SYM *text, uint2 *queue
   const bool go = nx != NONE || on;
   const uint64_t m = __ballot (go);
   if (go)
-    queue[base + rank_below (m)] = on ? make_uint2 (p, pk.x | WI_RECORD) : make_uint2 (p + 1, nx | (GRAM ? WI_RECORD : 0u));
+    queue[base + rank_below (m)] = on ? make_uint2 (p, pk.x | WI_RECORD | (GRAM == 2 && K.peek_rel ? next_cls << 24 : 0u))
+                                      : make_uint2 (p + 1, nx | (GRAM ? WI_RECORD : 0u) | (GRAM == 2 && K.peek_rel ? 31u << 24 : 0u));
   const uint32_t fill = base + (uint32_t)__popcll (m);
   if (COUNT_ONLY)
     return ((unsigned long long)fill << 32) | (uint32_t)counted;
