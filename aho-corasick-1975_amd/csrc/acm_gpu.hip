@@ -1528,7 +1528,7 @@ launch_starts (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_
 
 template <bool COUNT_ONLY>
 int
-launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop) {
+launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop, bool first_segment, bool last_segment) {
   const uint32_t group = WAVE * 16;
   const uint32_t ngroups = (uint32_t)(((uint64_t)a.n + group - 1) / group);
   uint32_t grid = (uint32_t)p->cu_count;
@@ -1555,14 +1555,20 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t 
   void *items = (COUNT_ONLY || direct) ? nullptr : p->d_items;
   uint32_t *fill = (COUNT_ONLY || direct) ? nullptr : p->d_fill;
   void *holes = (!COUNT_ONLY && direct) ? p->d_holes : nullptr;
-  void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill, &holes };
+  /* the segments of one scan share the waves' chunks of records: a wave picks up in segment k + 1
+   * the chunk it was filling at the end of segment k (its hole descriptor says where), and the
+   * holes are closed once, behind the last segment */
+  uint32_t resume = first_segment ? 0u : 1u;
+  if (holes && first_segment)
+    HIP_TRY (hipMemsetAsync (holes, 0, (size_t)p->direct_regions * sizeof (RecHole), st));
+  void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill, &holes, &resume };
   HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts, p->gram_wide), dim3 (grid), dim3 (SPARSE_THREADS), args,
                             p->gram_lds_bytes, st));
   if (stop)
     HIP_TRY (hipEventRecord (stop, st));
   if (!COUNT_ONLY) {
-    if (direct) {
-      const uint32_t n_waves = grid * wpb;
+    if (direct && last_segment) {
+      const uint32_t n_waves = p->direct_regions; /* (an earlier segment may have had more blocks than this one) */
       uint32_t npow = 64;
       while (npow < n_waves)
         npow <<= 1;
@@ -1570,7 +1576,7 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t 
       hipLaunchKernelGGL (close_holes_kernel, dim3 (blocks), dim3 (CLOSE_THREADS), npow * 16, st, E, static_cast<const RecHole *> (p->d_holes),
                           n_waves, npow, reinterpret_cast<unsigned int *> (p->d_total + 1));
       HIP_TRY (hipGetLastError ());
-    } else
+    } else if (!direct)
       launch_expand_hits (p, E, grid * wpb, st);
   }
   return ACM_GPU_OK;
@@ -2209,7 +2215,7 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
       a.range_begin = 0;
       a.range_end = a.n;
       if (p->gram)
-        rc = launch_gram<COUNT_ONLY> (p, E, a, st, stop);
+        rc = launch_gram<COUNT_ONLY> (p, E, a, st, stop, seg == first_seg, seg_end == n);
       else if (p->starts && (reinterpret_cast<uintptr_t> (a.text) & 15) == 0)
         rc = launch_starts<COUNT_ONLY> (p, E, a, st, stop);
       else {

@@ -130,7 +130,7 @@ gram_item_word (const uint32_t (&c)[20], int j, uint32_t idx) {
 template <bool COUNT_ONLY, bool SHORTS, bool WIDE>
 __global__ __launch_bounds__ (SPARSE_THREADS) void
 scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
-                  uint32_t *fill, RecHole *holes) {
+                  uint32_t *fill, RecHole *holes, uint32_t resume) {
   extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
   constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
   constexpr uint32_t GROUP = WAVE * 16;
@@ -179,8 +179,29 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   if (!DIRECT)
     hits_init (hits, (!COUNT_ONLY && items) ? items + (size_t)wave_id * region_items : nullptr, region_items, lane);
   else if (lane == 0) {
+    /* no chunk yet (limit 0 sends the first batch through emit_records_slow) -- or, in a later
+     * segment of the same scan (`resume`), the chunk this wave was filling when the segment before
+     * ended: what it had left of it is in its hole descriptor.  The holes of a scan are closed once,
+     * behind its last segment (seven fewer close_holes_kernel launches per 16 GiB). */
     WaveRec w0{};
-    Ws[wib] = w0; /* no chunk yet: limit 0 sends the first batch through emit_records_slow */
+    if (resume && !COUNT_ONLY && holes) {
+      const RecHole h = holes[wave_id];
+      if (h.len) {
+        const unsigned long long at = ((unsigned long long)h.start_hi << 32) | h.start_lo; /* first free slot */
+        const unsigned long long base = at + h.len - REC_CHUNK;
+        const bool below = base + REC_CHUNK <= E.capacity;
+        const bool above = base >= E.capacity && base - E.capacity + REC_CHUNK <= E.spill_slots;
+        const uint64_t dst = below ? reinterpret_cast<uint64_t> (&E.records[base]) : (above ? reinterpret_cast<uint64_t> (E.spill + (base - E.capacity)) : 0ull);
+        w0.dst_lo = (uint32_t)dst;
+        w0.dst_hi = (uint32_t)(dst >> 32);
+        w0.base_lo = (uint32_t)base;
+        w0.base_hi = (uint32_t)(base >> 32);
+        w0.limit = (below || above) ? REC_CHUNK : 0u;
+        w0.have = 1;
+        w0.pad[0] = REC_CHUNK - h.len; /* slots used */
+      }
+    }
+    Ws[wib] = w0;
   }
   const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
   /* block b takes the tiles b, b + gridDim.x, ... (match density is rarely even along a text:
@@ -189,11 +210,17 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   const TileShare share (A);
   const uint32_t last_blk = (A.n - 1) / 16;
   uint32_t qn1 = 0, qn2 = 0, qn3 = 0;
+#if ACM_GRAM_PUSH2
   uint32_t fill1 = 0; /* narrow alphabets: the first queue's fill as the pushes keep it, in a vector register */
   asm volatile ("" : "+v"(fill1));
   const uint32_t q1_lds = (uint32_t)(uintptr_t)(K.queue_off + wib * GRAM_Q1 * 8u); /* LDS address of this wave's first queue (LDS starts at 0: no static LDS here) */
+#endif
   unsigned long long counted = 0;
-  RecState rs = { 0ull, 0u }; /* DIRECT: the wave's chunk of records (no chunk yet) */
+  RecState rs = { 0ull, 0u }; /* DIRECT: the wave's chunk of records (none yet, or the one a resumed scan left) */
+  if (DIRECT && !COUNT_ONLY && resume) {
+    rs = rec_state_load (hits);
+    counted = uniform (reinterpret_cast<const WaveRec *> (hits)->pad[0]);
+  }
   /* batches of the first queue whose records are in flight: a pipeline of GRAM_DEPTH batches
    * (the gather of a batch has the time it takes the scan to fill that many more before it is
    * looked at: one batch ahead left the L2 / MALL latency exposed).  Narrow alphabets: the record

@@ -148,11 +148,10 @@ constexpr uint32_t ORDER_SMALL = 256; /* records a wave orders by itself: 4 per 
 /* the wave puts the cnt <= 256 records bucketed[base ...] in order into out[base ...]: a record's
  * place is the number of records with a smaller key (position from `lo` on, then longer before
  * shorter; keys differ).  KEY = uint32_t when the positions span at most a bucket. */
-template <typename KEY>
+template <typename KEY, int R>
 __device__ __forceinline__ void
-order_wave_sort (const OrderK &K, uint64_t lo, uint32_t base, uint32_t cnt, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out,
-                 uint32_t lane) {
-  constexpr int R = ORDER_SMALL / WAVE;
+order_wave_sort_r (const OrderK &K, uint64_t lo, uint32_t base, uint32_t cnt, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out,
+                   uint32_t lane) {
   uint4 rec[R];
   KEY key[R];
   uint32_t rank[R];
@@ -188,6 +187,19 @@ order_wave_sort (const OrderK &K, uint64_t lo, uint32_t base, uint32_t cnt, cons
   for (int r = 0; r < R; r++)
     if ((uint32_t)r * WAVE + lane < cnt)
       *reinterpret_cast<uint4 *> (&out[base + rank[r]]) = rec[r];
+}
+
+/* (R = records per lane: a bucket of 100 records costs half the compares of one of 256) */
+template <typename KEY>
+__device__ __forceinline__ void
+order_wave_sort (const OrderK &K, uint64_t lo, uint32_t base, uint32_t cnt, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out,
+                 uint32_t lane) {
+  if (cnt <= WAVE)
+    order_wave_sort_r<KEY, 1> (K, lo, base, cnt, bucketed, out, lane);
+  else if (cnt <= 2 * WAVE)
+    order_wave_sort_r<KEY, 2> (K, lo, base, cnt, bucketed, out, lane);
+  else
+    order_wave_sort_r<KEY, 4> (K, lo, base, cnt, bucketed, out, lane);
 }
 
 /* dense record sets: a wave per bucket of up to 256 records */

@@ -96,7 +96,7 @@ def launch_workers(args):
 
 def known_answer(config, n_symbols_rank0):
     """(below, count, digest) of the largest committed oracle answer (tests/golden/known_answers.json,
-    made by tools/known_answers.py in the build container) that lies inside rank 0's text, or None."""
+    made by tests/golden/make_known_answers.py in the build container) that lies inside rank 0's text, or None."""
     if not os.path.exists(KNOWN_ANSWERS):
         return None
     with open(KNOWN_ANSWERS) as f:
@@ -206,7 +206,7 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
         got = (full_count, full_digest) if below == n_own else acm.synth.device_digest(records, n_matches, below=below)
         assert got == (kc, kdg), "config %d: records with end_pos < %d differ from the oracle's known answer: %d / %#x, expected %d / %#x" % (
             config, below, got[0], got[1], kc, kdg)
-        checked = "oracle (AC-75 variant, tools/known_answers.py -> tests/golden/known_answers.json), %s: %d / %#018x" % (
+        checked = "oracle (AC-75 variant, tests/golden/make_known_answers.py -> tests/golden/known_answers.json), %s: %d / %#018x" % (
             "whole text" if below == n_own else "records ending in the first %d symbols" % below, kc, kdg)
 
     # ---- end-to-end leg: scan + canonical order + gather of records to rank 0 (separately timed)
@@ -301,7 +301,7 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
                     sym, int(rec_bytes_scan), "the 16-byte records themselves" if direct else
                     "8-byte items / hits parked for %s, which writes the 16-byte records" % FOLLOWERS.get(info["kernel"], "the kernel behind it")),
                 "behind_it": {"kernel": FOLLOWERS.get(info["kernel"]), "avg_ms": round(follow_avg_ms, 4),
-                              "what": "HIP events on the launch stream: end of the scan kernel -> end of the kernel it is followed by"},
+                              "what": "HIP events on the launch stream: end of the scan kernel -> end of the kernel it is followed by, averaged over the launches (of a scan's launches only the last one is followed by close_holes_kernel)"},
             },
         }
         if e2e_obj:

@@ -2,10 +2,10 @@
 """Known answers of the BASELINE configs at FULL size, computed on the CPU with the oracle
 (oracle/ac_oracle.c, the restatement of /root/reference/aho_corasick.c) -- run in the build
 container, results committed as tests/golden/known_answers.json and asserted by the full-size GPU
-tests and by bench.py.
+tests and by bench.py.  Test infrastructure (it drives the oracle): it lives under tests/.
 
-  python tools/known_answers.py --config 5            # 2^30 uint32 tokens, 10k keywords
-  python tools/known_answers.py --config 3 --mib 4096 # first 4 GiB of config 3's 16 GiB
+  python tests/golden/make_known_answers.py --config 5            # 2^30 uint32 tokens, 10k keywords
+  python tests/golden/make_known_answers.py --config 3 --mib 4096 # first 4 GiB of config 3's 16 GiB
 
 The text is generated piece by piece with the numpy generator (aho-corasick-1975_amd/synth.py, not
 the device generator the GPU runs use), every piece scanned with an overlap of lmax - 1 symbols of
@@ -19,7 +19,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 

@@ -495,6 +495,33 @@ def test_segment_seams(torch_cuda, monkeypatch):
     assert np.array_equal(m4.plan(0).scan_sorted(_dev(torch_cuda, t4)), o4.scan(t4))
 
 
+def test_gram_record_chunks_carried_across_segments(torch_cuda, monkeypatch):
+    """The 4-gram kernel's waves keep the chunk of record slots they are filling from one launch
+    segment of a scan to the next and the holes are closed once behind the last segment: a text of
+    24 segments full of matches, whole, from a cut, and into a buffer that is too small (chunks
+    that begin in the buffer and end in the spill area, carried over a seam)."""
+    monkeypatch.setenv("ACM_GPU_SEGMENT_LOG2", "17")
+    rng = np.random.default_rng(4242)
+    kws = [rng.integers(97, 104, size=rng.integers(4, 13)).astype(np.uint8) for _ in range(12000)]
+    text = rng.integers(96, 105, size=24 * (1 << 17) + 12345).astype(np.uint8)
+    m, o = build_pair(kws, 1)
+    plan = m.plan(0)
+    assert plan.info.kernel == 5 and plan.info.records_direct == 1
+    want = o.scan(text)
+    assert want.size > 200000
+    dev = _dev(torch_cuda, text)
+    assert np.array_equal(plan.scan_sorted(dev), want)
+    cut = 7 * (1 << 17) + 999
+    assert np.array_equal(plan.scan_sorted(dev, emit_from=cut), want[want["end_pos"] >= cut])
+    for cap in (1, 1000, want.size // 3, want.size - 1):
+        rec, cnt = plan.scan(dev, capacity=cap)
+        assert int(cnt.item()) == want.size and rec.shape[0] == cap
+        plan.status()
+    assert np.array_equal(plan.scan_sorted(dev, capacity=want.size // 3), want)      # grows and repeats
+    assert np.array_equal(plan.scan_sorted(dev, capacity=want.size), want)          # exactly enough
+    assert int(plan.count(dev).item()) == want.size
+
+
 def _checksums(torch, rec, n):
     """order-independent fingerprints of the first n records of an int64 [cap, 2] device buffer"""
     r = rec[:n]
@@ -507,7 +534,7 @@ def _checksums(torch, rec, n):
 
 def _known_answers(config):
     """the oracle's answers at full size: tests/golden/known_answers.json, made in the build
-    container by tools/known_answers.py (count and digest of the records ending below every GiB)"""
+    container by tests/golden/make_known_answers.py (count and digest of the records ending below every GiB)"""
     import json
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "known_answers.json")
     with open(path) as f:

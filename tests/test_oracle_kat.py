@@ -247,7 +247,7 @@ def test_variants_agree_on_tables():
 
 
 def test_pieces_with_overlap_add_up_to_the_whole():
-    """orc_scan_mt_at -- what tools/known_answers.py sums over the pieces of a full-size text: a piece
+    """orc_scan_mt_at -- what tests/golden/make_known_answers.py sums over the pieces of a full-size text: a piece
     that starts with lmax - 1 symbols of its predecessor (warm-up only) and reports global positions;
     count and digest of the pieces add up to those of the whole, for any cut and thread count.  Also
     what the committed full-size answers rest on: the file's config 2 total is the 555,000 /
