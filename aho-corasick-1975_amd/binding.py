@@ -73,7 +73,7 @@ EXPORTS = [
     "acm_flat_dense_rows", "acm_flat_blob_bytes", "acm_flat_to_blob", "acm_flat_from_blob", "acm_flat_save",
     "acm_flat_load", "acm_flat_keyword", "acm_flatten_classes", "acm_gpu_plan_create_classes", "acm_gpu_plan_create", "acm_gpu_plan_create_flat", "acm_gpu_plan_update", "acm_gpu_plan_destroy",
     "acm_gpu_plan_info", "acm_gpu_scan_device", "acm_gpu_count_device", "acm_gpu_sort_tmp_bytes",
-    "acm_gpu_sort_records_device", "acm_gpu_order_tmp_bytes", "acm_gpu_order_records_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
+    "acm_gpu_sort_records_device", "acm_gpu_order_tmp_bytes", "acm_gpu_order_records_device", "acm_gpu_scan_ordered_tmp_bytes", "acm_gpu_scan_ordered_device", "acm_gpu_scan_host", "acm_scan", "acm_gpu_plan_timing",
     "acm_gpu_plan_timing_read", "acm_gpu_plan_timing_read_all", "acm_gpu_plan_status", "acm_gpu_synth_text",
     "acm_gpu_stream_open", "acm_gpu_stream_feed", "acm_gpu_stream_finish", "acm_gpu_stream_close",
     "acm_gpu_multi_create", "acm_gpu_multi_destroy", "acm_gpu_multi_shard_bounds", "acm_gpu_multi_scan_host",
@@ -169,6 +169,10 @@ def lib():
     L.acm_gpu_order_tmp_bytes.argtypes = [vp, u64, u64]
     L.acm_gpu_order_records_device.restype = i32
     L.acm_gpu_order_records_device.argtypes = [vp, vp, u64, u64, u64, vp, sz, vp]
+    L.acm_gpu_scan_ordered_tmp_bytes.restype = sz
+    L.acm_gpu_scan_ordered_tmp_bytes.argtypes = [vp, u64, u64]
+    L.acm_gpu_scan_ordered_device.restype = i32
+    L.acm_gpu_scan_ordered_device.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, vp, sz, vp]
     L.acm_gpu_scan_host.restype = i32
     L.acm_gpu_scan_host.argtypes = [vp, vp, u64, u64, u64, vp, u64, C.POINTER(u64)]
     L.acm_scan.restype = i32
@@ -505,6 +509,27 @@ class Plan:
                                          records.shape[0], count.data_ptr(), self._stream()), "acm_gpu_scan_device")
         return records, count
 
+    def scan_ordered(self, text, n_symbols=None, emit_from=0, pos_base=0, capacity=None, records=None, count=None, tmp=None):
+        """acm_gpu_scan_ordered_device(): scan + canonical order, queued on the current stream with
+        no host round trip in between (the order passes read the count on the device).  Returns
+        (records, count, tmp); records[:count] is in canonical order when count <= capacity."""
+        import torch
+        assert text.is_cuda and text.is_contiguous()
+        if n_symbols is None:
+            n_symbols = text.numel() * text.element_size() // self.sym_size
+        if records is None:
+            cap = int(capacity) if capacity is not None else max(4096, n_symbols // 256)
+            records = torch.empty((cap, 2), dtype=torch.int64, device=text.device)
+        if count is None:
+            count = torch.zeros(1, dtype=torch.int64, device=text.device)
+        tb = lib().acm_gpu_scan_ordered_tmp_bytes(self.h, records.shape[0], n_symbols)
+        if tmp is None or tmp.numel() < tb:
+            tmp = torch.empty(tb, dtype=torch.uint8, device=text.device)
+        _check(lib().acm_gpu_scan_ordered_device(self.h, text.data_ptr(), n_symbols, emit_from, pos_base, records.data_ptr(),
+                                                 records.shape[0], count.data_ptr(), tmp.data_ptr(), tmp.numel(), self._stream()),
+               "acm_gpu_scan_ordered_device")
+        return records, count, tmp
+
     def count(self, text, n_symbols=None, emit_from=0, count=None):
         import torch
         if n_symbols is None:
@@ -535,19 +560,23 @@ class Plan:
                "acm_gpu_order_records_device")
         return records
 
-    def scan_sorted(self, text, n_symbols=None, emit_from=0, pos_base=0, capacity=None):
-        """Scan + canonical sort; grows the record buffer when it overflowed (nothing is dropped).
-        Returns a numpy structured array (RECORD_DTYPE)."""
-        import torch
+    def scan_sorted(self, text, n_symbols=None, emit_from=0, pos_base=0, capacity=None, fused=True):
+        """Scan + canonical order; grows the record buffer when it overflowed (nothing is dropped).
+        fused: acm_gpu_scan_ordered_device (one call), else acm_gpu_scan_device, the count read
+        back, acm_gpu_order_records_device.  Returns a numpy structured array (RECORD_DTYPE)."""
         cap = capacity
         while True:
-            rec, cnt = self.scan(text, n_symbols, emit_from, pos_base, cap)
+            if fused:
+                rec, cnt, _ = self.scan_ordered(text, n_symbols, emit_from, pos_base, cap)
+            else:
+                rec, cnt = self.scan(text, n_symbols, emit_from, pos_base, cap)
             n = int(cnt.item())
             if n > rec.shape[0]:
                 cap = n
                 continue
-            ns = n_symbols if n_symbols is not None else text.numel() * text.element_size() // self.sym_size
-            self.sort(rec, n, pos_base, ns)
+            if not fused:
+                ns = n_symbols if n_symbols is not None else text.numel() * text.element_size() // self.sym_size
+                self.sort(rec, n, pos_base, ns)
             self.status()
             return np.frombuffer(rec[:n].cpu().numpy().tobytes(), dtype=RECORD_DTYPE).copy()
 

@@ -74,6 +74,9 @@ constexpr uint32_t GRAM_Q2 = 96;    /* 4-gram kernel: per-wave queue of walk can
 /* 4-gram kernel: its first queue.  -DACM_GRAM_PUSH2=1 (experiment, measured 9.6 % SLOWER: 2.425
  * against 2.213 ms per 2 GiB of config 3) builds the branch-free push of dev_gram.h, whose queue
  * holds 63 waiting + 2 x 64 pushed items; the product is built without it */
+#ifndef ACM_GRAM_PUSH4
+#define ACM_GRAM_PUSH4 0
+#endif
 #ifndef ACM_GRAM_PUSH2
 #define ACM_GRAM_PUSH2 0
 #endif
@@ -2542,7 +2545,7 @@ order_layout (const ACMPlan *plan, uint64_t n, uint64_t span) {
   uint32_t wlog = 0;
   while ((2u << wlog) <= ORDER_POSITIONS && (1ull << wlog) < span)
     wlog++;
-  L.sparse = (double)n * 4096.0 < 8.0 * (double)span;
+  L.sparse = order_is_sparse (n, span);
   const uint64_t nb = (span >> wlog) + 1;
   if (nb >= (1ull << 28) || span_bits + len_bits > 63 || wlog + len_bits > 31) /* (a bucket's keys are 32-bit) */
     return L;
@@ -2552,8 +2555,8 @@ order_layout (const ACMPlan *plan, uint64_t n, uint64_t span) {
   (void)hipcub::DeviceScan::ExclusiveSum (nullptr, cub, static_cast<uint32_t *> (nullptr), static_cast<uint32_t *> (nullptr), (int)(nb + 1), nullptr);
   L.cub_bytes = cub;
   size_t cur = 0;
-  L.o_hist = blob_reserve (cur, (nb + 1) * 4);
-  L.o_cur = blob_reserve (cur, (nb + 1) * 4);
+  L.o_hist = blob_reserve (cur, (nb + 1) * 4 + (nb + 2) * 4); /* counts, then (o_cur, right behind them) a zero word and the sums */
+  L.o_cur = L.o_hist + (nb + 1) * 4;
   L.o_rec = blob_reserve (cur, n * sizeof (ACMRecord));
   L.o_cub = blob_reserve (cur, cub + 16);
   L.total = cur + 256;
@@ -2571,19 +2574,27 @@ acm_gpu_order_tmp_bytes (const ACMPlan *plan, uint64_t n, uint64_t span) {
   return L.ok && L.total > radix ? L.total : radix; /* (room for the fallback either way) */
 }
 
-extern "C" int
-acm_gpu_order_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, uint64_t pos_lo, uint64_t span, void *d_tmp,
-                              size_t tmp_bytes, void *stream) {
-  if (!plan || (n && (!d_records || !d_tmp)))
-    return ACM_GPU_E_ARG;
-  if (n <= 1)
-    return ACM_GPU_OK;
+namespace {
+/* n_dev == nullptr: n records.  Else: the record count is the scan's, in device memory, and n the
+ * capacity of d_records (OrderK::n_dev) -- nothing here waits for the host. */
+bool
+order_by_buckets (const ACMPlan *plan, const OrderPlan &L) {
+  const char *env = getenv ("ACM_GPU_ORDER"); /* radix: always the radix sort (experiments, tests) */
+  (void)plan;
+  return L.ok && !(env && strcmp (env, "radix") == 0);
+}
+
+int
+order_records (ACMPlan *plan, ACMRecord *d_records, uint64_t n, const unsigned long long *n_dev, uint64_t pos_lo, uint64_t span, void *d_tmp,
+               size_t tmp_bytes, void *stream) {
   if (tmp_bytes < acm_gpu_order_tmp_bytes (plan, n, span))
     return ACM_GPU_E_ARG;
   const OrderPlan L = order_layout (plan, n, span);
-  const char *env = getenv ("ACM_GPU_ORDER"); /* radix: always the radix sort (experiments, tests) */
-  if (!L.ok || (env && strcmp (env, "radix") == 0))
+  if (!order_by_buckets (plan, L)) {
+    if (n_dev)
+      return ACM_GPU_E_ARG; /* (the caller asks order_by_buckets first) */
     return radix_sort_records (plan, d_records, n, d_tmp, tmp_bytes, stream, pos_lo, L.key_bits);
+  }
   HIP_TRY (hipSetDevice (plan->device));
   hipStream_t st = static_cast<hipStream_t> (stream);
   unsigned char *t = static_cast<unsigned char *> (d_tmp);
@@ -2597,32 +2608,78 @@ acm_gpu_order_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, u
   K.n_buckets = L.n_buckets;
   K.len_bits = L.len_bits;
   K.error = plan->d_total ? reinterpret_cast<unsigned int *> (plan->d_total) + 3 : nullptr;
-  HIP_TRY (hipMemsetAsync (hist, 0, ((size_t)L.n_buckets + 1) * 4, st));
+  K.n_dev = n_dev;
+  K.span = span;
+  K.mode = n_dev ? 2u : (L.sparse ? 1u : 0u);
+  /* `hist`: the buckets' counts (pass A).  `cur`: one word that stays 0, then the buckets' exclusive
+   * prefix sums -- where each bucket begins, the cursors pass B advances; when it is done cur[1 + b]
+   * is where bucket b ENDS, so that P = cur reads P[b] = begin, P[b + 1] = end for pass C (no copy
+   * of the sums is kept) */
+  HIP_TRY (hipMemsetAsync (hist, 0, ((size_t)L.n_buckets + 2) * 4, st)); /* (the counts and cur[0], which lies right behind them) */
   const uint64_t pieces = (n + ORDER_PIECE - 1) / ORDER_PIECE, pblocks = (pieces + ORDER_THREADS / WAVE - 1) / (ORDER_THREADS / WAVE);
   const uint32_t grid = (uint32_t)(pblocks < (uint64_t)plan->cu_count * 8 ? pblocks : (uint64_t)plan->cu_count * 8);
   hipLaunchKernelGGL (order_bucket_kernel<false>, dim3 (grid), dim3 (ORDER_THREADS), 0, st, K, hist, static_cast<ACMRecord *> (nullptr));
   HIP_TRY (hipGetLastError ());
   size_t cub = L.cub_bytes;
-  HIP_TRY (hipcub::DeviceScan::ExclusiveSum (t + L.o_cub, cub, hist, cur, (int)(L.n_buckets + 1), st));
-  /* `cur` = where every bucket begins (and, at n_buckets, ends): pass C reads it; pass B advances a copy */
-  HIP_TRY (hipMemcpyAsync (hist, cur, ((size_t)L.n_buckets + 1) * 4, hipMemcpyDeviceToDevice, st));
-  hipLaunchKernelGGL (order_bucket_kernel<true>, dim3 (grid), dim3 (ORDER_THREADS), 0, st, K, hist, bucketed);
+  HIP_TRY (hipcub::DeviceScan::ExclusiveSum (t + L.o_cub, cub, hist, cur + 1, (int)(L.n_buckets + 1), st));
+  hipLaunchKernelGGL (order_bucket_kernel<true>, dim3 (grid), dim3 (ORDER_THREADS), 0, st, K, cur + 1, bucketed);
   HIP_TRY (hipGetLastError ());
   /* pass C: buckets (dense record sets) or windows of buckets (sparse ones) of up to 256 records by
-   * a wave each, crowded buckets by a block each (each kernel skips the other's) */
-  if (L.sparse) {
+   * a wave each, crowded buckets by a block each (each role skips the others' buckets) */
+  uint32_t wgrid = 0, sgrid = 0;
+  if (n_dev || L.sparse) { /* (with the count on the device both are there: the one whose kind of set it is not returns at once) */
     const uint64_t windows = (n + ORDER_WINDOW - 1) / ORDER_WINDOW, wblocks = (windows + 3) / 4;
-    const uint32_t wgrid = (uint32_t)(wblocks < (uint64_t)plan->cu_count * 16 ? wblocks : (uint64_t)plan->cu_count * 16);
-    hipLaunchKernelGGL (order_window_kernel, dim3 (wgrid), dim3 (256), 0, st, K, cur, bucketed, d_records);
-  } else {
-    const uint32_t sgrid = (uint32_t)((L.n_buckets + 3) / 4 < (uint32_t)plan->cu_count * 16 ? (L.n_buckets + 3) / 4 : (uint32_t)plan->cu_count * 16);
-    hipLaunchKernelGGL (order_small_kernel, dim3 (sgrid), dim3 (256), 0, st, K, cur, bucketed, d_records);
+    wgrid = (uint32_t)(wblocks < (uint64_t)plan->cu_count * 16 ? wblocks : (uint64_t)plan->cu_count * 16);
   }
+  if (n_dev || !L.sparse)
+    sgrid = (uint32_t)((L.n_buckets + 3) / 4 < (uint32_t)plan->cu_count * 16 ? (L.n_buckets + 3) / 4 : (uint32_t)plan->cu_count * 16);
   const uint32_t cblocks = (L.n_buckets + ORDER_COUNT_THREADS - 1) / ORDER_COUNT_THREADS;
   const uint32_t cgrid = cblocks < (uint32_t)plan->cu_count * 8 ? cblocks : (uint32_t)plan->cu_count * 8;
-  hipLaunchKernelGGL (order_count_kernel, dim3 (cgrid), dim3 (ORDER_COUNT_THREADS), 0, st, K, cur, bucketed, d_records);
+  hipLaunchKernelGGL (order_finish_kernel, dim3 (wgrid + sgrid + cgrid), dim3 (256), 0, st, K, cur, bucketed, d_records, wgrid, sgrid);
   HIP_TRY (hipGetLastError ());
   return ACM_GPU_OK;
+}
+} // namespace
+
+extern "C" int
+acm_gpu_order_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, uint64_t pos_lo, uint64_t span, void *d_tmp,
+                              size_t tmp_bytes, void *stream) {
+  if (!plan || (n && (!d_records || !d_tmp)))
+    return ACM_GPU_E_ARG;
+  if (n <= 1)
+    return ACM_GPU_OK;
+  return order_records (plan, d_records, n, nullptr, pos_lo, span, d_tmp, tmp_bytes, stream);
+}
+
+/* Scan and canonical order in one call, nothing but kernel launches on `stream`: the order passes
+ * take the number of records from *d_count on the device.  A scan that overflows `capacity` leaves
+ * the total in *d_count as acm_gpu_scan_device does and nothing in order (the caller repeats it with
+ * room).  Record sets the bucket passes do not take (2^31 records or more, positions past 2^63 /
+ * lengths): the count comes to the host and acm_gpu_order_records_device's fallback runs. */
+extern "C" size_t
+acm_gpu_scan_ordered_tmp_bytes (const ACMPlan *plan, uint64_t capacity, uint64_t n_symbols) {
+  return acm_gpu_order_tmp_bytes (plan, capacity, n_symbols);
+}
+
+extern "C" int
+acm_gpu_scan_ordered_device (ACMPlan *plan, const void *d_text, uint64_t n_symbols, uint64_t emit_from, uint64_t pos_base,
+                             ACMRecord *d_records, uint64_t capacity, uint64_t *d_count, void *d_tmp, size_t tmp_bytes, void *stream) {
+  if (!plan || !d_count || (n_symbols && !d_text) || (capacity && (!d_records || !d_tmp)))
+    return ACM_GPU_E_ARG;
+  if (capacity && tmp_bytes < acm_gpu_scan_ordered_tmp_bytes (plan, capacity, n_symbols))
+    return ACM_GPU_E_ARG;
+  int rc = acm_gpu_scan_device (plan, d_text, n_symbols, emit_from, pos_base, d_records, capacity, d_count, stream);
+  if (rc || capacity == 0 || n_symbols == 0)
+    return rc;
+  const OrderPlan L = order_layout (plan, capacity, n_symbols);
+  if (order_by_buckets (plan, L))
+    return order_records (plan, d_records, capacity, reinterpret_cast<const unsigned long long *> (d_count), pos_base, n_symbols, d_tmp, tmp_bytes, stream);
+  uint64_t found = 0;
+  HIP_TRY (hipMemcpyAsync (&found, d_count, 8, hipMemcpyDeviceToHost, static_cast<hipStream_t> (stream)));
+  HIP_TRY (hipStreamSynchronize (static_cast<hipStream_t> (stream)));
+  if (found <= 1 || found > capacity)
+    return ACM_GPU_OK;
+  return order_records (plan, d_records, found, nullptr, pos_base, n_symbols, d_tmp, tmp_bytes, stream);
 }
 
 /* ------------------------------------------------------------------ host-buffer convenience */

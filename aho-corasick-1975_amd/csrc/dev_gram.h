@@ -543,6 +543,10 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       }
       return;
     }
+#if defined(ACM_GRAM_ABLATE) && ACM_GRAM_ABLATE == 7 /* experiment: the text is streamed and not looked at */
+    asm volatile ("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
+    return;
+#endif
     uint32_t c[20];
 #pragma unroll
     for (int j = 0; j < 20; j++) {
@@ -576,7 +580,11 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       for (int j = 0; j < 8; j++) {
         const uint32_t idx = __umul24 (pair[8 * h + j], W2) + pair[8 * h + j + 2];
         ix[j] = idx;
+#if defined(ACM_GRAM_ABLATE) && ACM_GRAM_ABLATE == 6 /* experiment: classes and indices, no table look-up, no push */
+        word[j] = idx;
+#else
         word[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
+#endif
         if (SHORTS) {
           const uint32_t idx3 = __umul24 (pair[8 * h + j], K.W) + c[8 * h + j + 2];
           ix3[j] = idx3;
@@ -632,11 +640,63 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           }
         }
       }
+#elif ACM_GRAM_PUSH4
+      /* Four positions' survivors at a time: the four compares first, then the scalar unit's
+       * counts and running sums in one go, then four masked writes.  Position by position, every
+       * push was a chain vector compare -> scalar branch -> exec mask -> write -> scalar count ->
+       * add -> compare -> branch that a wave cannot overlap with anything (a scalar instruction
+       * that reads what a vector compare has just written waits ~35 cycles for it): the ablation
+       * builds price it at 0.42 of the kernel's 1.9 ms per 2 GiB, more than the classes, indices
+       * and table look-ups of all positions together.  If the four might overflow the queue (63
+       * waiting + 4 x 64 in the worst case; ~50 come on config 3) they go one by one. */
+#pragma unroll
+      for (int quad = 0; quad < 2; quad++) {
+        bool push[4];
+        uint64_t m[4];
+        uint32_t at[5];
+        at[0] = qn1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          push[j] = __builtin_amdgcn_ubfe (word[4 * quad + j], ix[4 * quad + j], 1u) != 0;
+          m[j] = __ballot (push[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          at[j + 1] = at[j] + (uint32_t)__popcll (m[j]);
+        if (__builtin_expect (at[4] <= GRAM_Q1, 1)) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (push[j])
+              q1[__builtin_amdgcn_mbcnt_hi ((uint32_t)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo ((uint32_t)m[j], at[j]))] =
+                  make_uint2 (pos0 + 8 * h + 4 * quad + j, gram_item_word (c, 8 * h + 4 * quad + j, ix[4 * quad + j]));
+          qn1 = uniform (at[4]);
+          while (__builtin_expect (qn1 >= WAVE, 0)) {
+            DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)
+            batch_step (WAVE);
+            DIAG (d_cons += __builtin_readcyclecounter () - d_c1; d_b1++;)
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (m[j]) {
+              if (push[j])
+                q1[qn1 + rank_below (m[j])] = make_uint2 (pos0 + 8 * h + 4 * quad + j, gram_item_word (c, 8 * h + 4 * quad + j, ix[4 * quad + j]));
+              qn1 = uniform (qn1 + (uint32_t)__popcll (m[j]));
+              if (qn1 >= WAVE)
+                batch_step (WAVE);
+            }
+          }
+        }
+      }
 #else
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const bool push = __builtin_amdgcn_ubfe (word[j], ix[j], 1u) != 0; /* v_bfe_u32 (it takes the low 5 bits of the offset itself) */
         const uint64_t m = __ballot (push);
+#if defined(ACM_GRAM_ABLATE) && (ACM_GRAM_ABLATE == 5 || ACM_GRAM_ABLATE == 6) /* experiment: the 4-gram bits are looked up, nothing is queued */
+        asm volatile ("" :: "s"(m));
+        continue;
+#endif
         if (m) {
           if (push)
             q1[qn1 + rank_below (m)] = make_uint2 (pos0 + 8 * h + j, gram_item_word (c, 8 * h + j, ix[j]));

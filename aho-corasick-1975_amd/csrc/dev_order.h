@@ -27,7 +27,31 @@ struct OrderK {
   uint32_t n_buckets;
   uint32_t len_bits;     /* bits of a length */
   unsigned int *error;   /* set when a record lies outside [pos_lo, pos_lo + span) */
+  /* a scan's records put in order behind it on the same stream, no host in between: the number of
+   * records is the scan's count in device memory (n is then the buffer's capacity: a count beyond
+   * it means the scan overflowed and is repeated -- nothing is put in order), and whether the set
+   * is sparse is decided here too (mode 2; 0: dense, 1: sparse) */
+  const unsigned long long *n_dev;
+  uint64_t span;
+  uint32_t mode;
 };
+
+__device__ __forceinline__ uint64_t
+order_n (const OrderK &K) {
+  if (!K.n_dev)
+    return K.n;
+  const unsigned long long c = *K.n_dev;
+  return c > K.n ? 0 : c;
+}
+/* fewer than 8 records per 4,096 positions: pass C goes by windows of buckets, not by bucket */
+__host__ __device__ __forceinline__ bool
+order_is_sparse (uint64_t n, uint64_t span) {
+  return n < (span >> 9);
+}
+__device__ __forceinline__ bool
+order_sparse (const OrderK &K, uint64_t n) {
+  return K.mode == 2 ? order_is_sparse (n, K.span) : K.mode == 1;
+}
 
 /* passes A (SCATTER = false: histogram into `hist`) and B (SCATTER = true: `hist` holds the buckets'
  * cursors, the records go to `out`).  A wave takes ORDER_PIECE = 512 consecutive records, eight per
@@ -45,7 +69,8 @@ __global__ __launch_bounds__ (ORDER_THREADS) void
 order_bucket_kernel (OrderK K, uint32_t *hist, ACMRecord *out) {
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves = (uint64_t)gridDim.x * blockDim.x / WAVE;
-  const uint64_t pieces = (K.n + ORDER_PIECE - 1) / ORDER_PIECE;
+  const uint64_t n = order_n (K);
+  const uint64_t pieces = (n + ORDER_PIECE - 1) / ORDER_PIECE;
   for (uint64_t piece = wave; piece < pieces; piece += waves) {
     const uint64_t first = piece * ORDER_PIECE;
     uint32_t b[ORDER_PER], rk[ORDER_PER];
@@ -56,7 +81,7 @@ order_bucket_kernel (OrderK K, uint32_t *hist, ACMRecord *out) {
       const uint64_t i = first + (uint64_t)q * WAVE + lane;
       b[q] = 0xFFFFFFFFu;
       rk[q] = 0;
-      if (i < K.n) {
+      if (i < n) {
         uint64_t pos;
         if (SCATTER) {
           rec[q] = *reinterpret_cast<const uint4 *> (&K.in[i]);
@@ -73,10 +98,21 @@ order_bucket_kernel (OrderK K, uint32_t *hist, ACMRecord *out) {
       }
       todo[q] = __ballot (b[q] != 0xFFFFFFFFu);
     }
-    /* up to ORDER_ROUNDS distinct buckets are taken one at a time (all their records in the piece
-     * counted by ballot, one atomic each); a piece whose records are spread wider than that --
-     * sparse matches: config 2 has two records per bucket -- hands the rest over lane by lane,
-     * every lane its own atomic, all of them in flight together */
+    /* up to ORDER_ROUNDS distinct buckets are taken one at a time: all their records in the piece
+     * are counted by ballot and the bucket gets ONE atomic for them.  Nothing here waits for an
+     * atomic: round r leaves its bucket and its count in lane r, every record remembers its round
+     * and its rank among that round's records, and when the rounds are over the lanes issue their
+     * atomics together (one memory round trip for the piece instead of one per round: 12 in a row
+     * made pass B 8.5 ms on config 3 and 33 us on the half a million records of config 2).  Four
+     * rounds that find two records each say the piece is spread thin (sparse matches: config 2 has
+     * two records per bucket) -- the rest goes lane by lane, every lane its own atomic.  (One
+     * thin round says nothing: a dense piece has stragglers in the bucket next door, and the 200
+     * records behind them must not go to ONE counter one by one -- that was 27 ms.) */
+    uint32_t rnd[ORDER_PER], rel[ORDER_PER];
+#pragma unroll
+    for (int q = 0; q < ORDER_PER; q++)
+      rnd[q] = 0xFFFFFFFFu, rel[q] = 0;
+    uint32_t my_bucket = 0, my_total = 0, rounds = 0, placed = 0;
     for (int round = 0; round < ORDER_ROUNDS; round++) {
       /* the bucket of the first record not yet placed */
       uint32_t b0 = 0xFFFFFFFFu;
@@ -86,34 +122,49 @@ order_bucket_kernel (OrderK K, uint32_t *hist, ACMRecord *out) {
           b0 = __builtin_amdgcn_readlane (b[q], (uint32_t)__builtin_ctzll (todo[q]));
       if (b0 == 0xFFFFFFFFu)
         break;
-      uint64_t m[ORDER_PER];
       uint32_t total = 0;
 #pragma unroll
       for (int q = 0; q < ORDER_PER; q++) {
-        m[q] = __ballot (b[q] == b0);
-        total += (uint32_t)__popcll (m[q]);
-        todo[q] &= ~m[q];
-      }
-      uint32_t at = 0;
-      if (lane == 0)
-        at = atomicAdd (&hist[b0], total); /* pass B: where this piece's run in the bucket begins */
-      if (SCATTER) {
-        at = __builtin_amdgcn_readfirstlane (at);
-#pragma unroll
-        for (int q = 0; q < ORDER_PER; q++) {
-          if (b[q] == b0)
-            rk[q] = at + rank_below (m[q]);
-          at += (uint32_t)__popcll (m[q]);
+        const uint64_t m = __ballot (b[q] == b0);
+        if (b[q] == b0) {
+          rnd[q] = (uint32_t)round;
+          rel[q] = total + rank_below (m);
         }
+        total += (uint32_t)__popcll (m);
+        todo[q] &= ~m;
       }
+      if (lane == (uint32_t)round) {
+        my_bucket = b0;
+        my_total = total;
+      }
+      rounds = (uint32_t)round + 1;
+      placed += total;
+      if (round == 3 && placed <= 8)
+        break;
+    }
+    uint32_t at = 0;
+    if (lane < rounds) {
+      if (SCATTER)
+        at = atomicAdd (&hist[my_bucket], my_total); /* pass B: where this piece's run in the bucket begins */
+      else
+        atomicAdd (&hist[my_bucket], my_total);
     }
 #pragma unroll
     for (int q = 0; q < ORDER_PER; q++)
       if ((todo[q] >> lane) & 1ull) {
-        const uint32_t at = atomicAdd (&hist[b[q]], 1u);
         if (SCATTER)
-          rk[q] = at;
+          rk[q] = atomicAdd (&hist[b[q]], 1u);
+        else
+          atomicAdd (&hist[b[q]], 1u);
       }
+    if (SCATTER) {
+#pragma unroll
+      for (int q = 0; q < ORDER_PER; q++) {
+        const uint32_t begins = __shfl (at, (int)(rnd[q] & (WAVE - 1)), WAVE);
+        if (rnd[q] != 0xFFFFFFFFu)
+          rk[q] = begins + rel[q];
+      }
+    }
     if (SCATTER) {
 #pragma unroll
       for (int q = 0; q < ORDER_PER; q++)
@@ -203,10 +254,13 @@ order_wave_sort (const OrderK &K, uint64_t lo, uint32_t base, uint32_t cnt, cons
 }
 
 /* dense record sets: a wave per bucket of up to 256 records */
-__global__ __launch_bounds__ (256) void
-order_small_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out) {
+__device__ __forceinline__ void
+order_small_role (const OrderK &K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out, uint32_t blk,
+                  uint32_t nblk) {
   const uint32_t lane = threadIdx.x & (WAVE - 1);
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves = gridDim.x * blockDim.x / WAVE;
+  const uint32_t wave = (blk * blockDim.x + threadIdx.x) / WAVE, waves = nblk * blockDim.x / WAVE;
+  if (order_sparse (K, order_n (K)))
+    return; /* order_window_kernel's */
   for (uint32_t b = wave; b < K.n_buckets; b += waves) {
     const uint32_t base = uniform (P[b]), cnt = uniform (P[b + 1]) - base;
     if (cnt == 0 || cnt > ORDER_SMALL)
@@ -221,25 +275,39 @@ order_small_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *_
  * bucket among sparse ones: the start of config 2's text has one of 934) its buckets one by one,
  * those of more than 256 left to order_count_kernel. */
 constexpr uint32_t ORDER_WINDOW = 128;
+/* the first bucket that begins at or after record `want` (P is ascending): the wave probes 64
+ * places of the range at a time -- three dependent loads for config 2's 262,144 buckets where a
+ * bisection took eighteen, and that was most of this kernel's 28 us */
 __device__ __forceinline__ uint32_t
-order_first_bucket_at (const uint32_t *__restrict__ P, uint32_t n_buckets, uint64_t want) {
+order_first_bucket_at (const uint32_t *__restrict__ P, uint32_t n_buckets, uint64_t want, uint32_t lane) {
   uint32_t lo = 0, hi = n_buckets;
   while (lo < hi) {
-    const uint32_t mid = lo + (hi - lo) / 2;
-    if (uniform (P[mid]) < want)
-      lo = mid + 1;
-    else
-      hi = mid;
+    const uint32_t step = (hi - lo + WAVE - 1) / WAVE;
+    const uint64_t idx = (uint64_t)lo + (uint64_t)lane * step;
+    const bool less = idx < hi && P[idx] < want;
+    const uint32_t c = (uint32_t)__popcll (__ballot (less)); /* (the probes that are less come first) */
+    if (c == 0)
+      hi = lo;
+    else {
+      const uint64_t first_not = (uint64_t)lo + (uint64_t)c * step;
+      lo = lo + (c - 1) * step + 1;
+      if (first_not < hi)
+        hi = (uint32_t)first_not;
+    }
   }
   return lo;
 }
-__global__ __launch_bounds__ (256) void
-order_window_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out) {
+__device__ __forceinline__ void
+order_window_role (const OrderK &K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out, uint32_t blk,
+                   uint32_t nblk) {
   const uint32_t lane = threadIdx.x & (WAVE - 1);
-  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves = (uint64_t)gridDim.x * blockDim.x / WAVE;
-  const uint64_t windows = (K.n + ORDER_WINDOW - 1) / ORDER_WINDOW;
+  const uint64_t wave = ((uint64_t)blk * blockDim.x + threadIdx.x) / WAVE, waves = (uint64_t)nblk * blockDim.x / WAVE;
+  const uint64_t n = order_n (K);
+  if (!order_sparse (K, n))
+    return; /* order_small_kernel's */
+  const uint64_t windows = (n + ORDER_WINDOW - 1) / ORDER_WINDOW;
   for (uint64_t k = wave; k < windows; k += waves) {
-    const uint32_t b0 = order_first_bucket_at (P, K.n_buckets, k * ORDER_WINDOW), b1 = order_first_bucket_at (P, K.n_buckets, (k + 1) * ORDER_WINDOW);
+    const uint32_t b0 = order_first_bucket_at (P, K.n_buckets, k * ORDER_WINDOW, lane), b1 = order_first_bucket_at (P, K.n_buckets, (k + 1) * ORDER_WINDOW, lane);
     if (b1 <= b0)
       continue;
     const uint32_t base = uniform (P[b0]), cnt = uniform (P[b1]) - base;
@@ -257,8 +325,8 @@ order_window_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *
   }
 }
 
-__global__ __launch_bounds__ (ORDER_COUNT_THREADS) void
-order_count_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *out) {
+__device__ __forceinline__ void
+order_count_role (const OrderK &K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *out, uint32_t blk, uint32_t nblk) {
   __shared__ uint32_t ctr[ORDER_POSITIONS];
   __shared__ uint32_t s_part[ORDER_COUNT_THREADS / WAVE];
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
@@ -268,7 +336,7 @@ order_count_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *_
    * crowded ones among them one by one: where there are none -- most of the time -- that is all */
   __shared__ uint32_t s_list[ORDER_COUNT_THREADS];
   __shared__ uint32_t s_nlist;
-  for (uint32_t first = blockIdx.x * ORDER_COUNT_THREADS; first < K.n_buckets; first += gridDim.x * ORDER_COUNT_THREADS) {
+  for (uint32_t first = blk * ORDER_COUNT_THREADS; first < K.n_buckets; first += nblk * ORDER_COUNT_THREADS) {
     if (tid == 0)
       s_nlist = 0;
     __syncthreads ();
@@ -339,3 +407,16 @@ order_count_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *_
   }
 }
 
+/* pass C in one launch: blocks [0, wgrid) take the windows of a sparse set, [wgrid, wgrid + sgrid)
+ * the buckets of a dense one (with the record count on the device both are there and the kind of
+ * set decides which of them works), the rest the crowded buckets */
+static_assert (ORDER_COUNT_THREADS == 256, "the three roles share a launch");
+__global__ __launch_bounds__ (256) void
+order_finish_kernel (OrderK K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *out, uint32_t wgrid, uint32_t sgrid) {
+  if (blockIdx.x < wgrid)
+    order_window_role (K, P, bucketed, out, blockIdx.x, wgrid);
+  else if (blockIdx.x < wgrid + sgrid)
+    order_small_role (K, P, bucketed, out, blockIdx.x - wgrid, sgrid);
+  else
+    order_count_role (K, P, bucketed, out, blockIdx.x - wgrid - sgrid, gridDim.x - wgrid - sgrid);
+}

@@ -214,10 +214,11 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
     if want_e2e:
         e2e_steps = max(1, min(steps, 5)) if n_matches < (1 << 24) else 1
 
-        def e2e():
-            plan.scan(text, n_scan, emit_from=halo, pos_base=pos_base, records=records, count=count)
+        order_tmp = [None]
+
+        def e2e():     # acm_gpu_scan_ordered_device: scan + order queued together, ONE wait (for the count) at the end
+            _, _, order_tmp[0] = plan.scan_ordered(text, n_scan, emit_from=halo, pos_base=pos_base, records=records, count=count, tmp=order_tmp[0])
             n = int(count.item())
-            plan.sort(records, n, pos_base, n_scan)
             return acm.sharded.gather_records(records[:n], dst=0) if world > 1 else records[:n]
 
         gathered = e2e()

@@ -237,6 +237,18 @@ size_t acm_gpu_order_tmp_bytes (const ACMPlan *plan, uint64_t n, uint64_t span);
 int acm_gpu_order_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, uint64_t pos_lo, uint64_t span,
                                   void *d_tmp, size_t tmp_bytes, void *stream);
 
+/* acm_gpu_scan_device and the canonical order of what it found in ONE call that only queues work on
+ * `stream`: the order passes read the number of records from *d_count on the device, so no host
+ * round trip separates the scan from them (the caller loop of aho_corasick.h:47,77 yields its
+ * matches in this order; this is that loop's output, complete, with one synchronisation at the
+ * end).  d_records[0 .. *d_count) is in canonical order afterwards when *d_count <= capacity; a
+ * scan that overflowed leaves the total in *d_count and nothing in order (repeat it with room).
+ * d_tmp must hold acm_gpu_scan_ordered_tmp_bytes(plan, capacity, n_symbols) bytes. */
+size_t acm_gpu_scan_ordered_tmp_bytes (const ACMPlan *plan, uint64_t capacity, uint64_t n_symbols);
+int acm_gpu_scan_ordered_device (ACMPlan *plan, const void *d_text, uint64_t n_symbols, uint64_t emit_from,
+                                 uint64_t pos_base, ACMRecord *d_records, uint64_t capacity, uint64_t *d_count,
+                                 void *d_tmp, size_t tmp_bytes, void *stream);
+
 /* Host-buffer convenience: upload, scan, sort, download; blocking.  On ACM_GPU_E_OVERFLOW
  * *n_found holds the capacity needed. */
 int acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint64_t emit_from,

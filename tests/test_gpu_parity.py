@@ -325,6 +325,59 @@ def test_order_records_by_buckets_equals_a_plain_sort(torch_cuda, shape):
     plan.status()
 
 
+@pytest.mark.parametrize("kind", ["dense", "gram", "starts16"])
+def test_scan_ordered_one_call_equals_scan_then_order(torch_cuda, monkeypatch, kind):
+    """acm_gpu_scan_ordered_device: scan and canonical order queued in one call (the order passes read
+    the count on the device; both pass-C kernels are launched and the set's kind decides on the
+    device which of them works).  Sparse and dense record sets, no records at all, one record, a
+    buffer that is too small (total reported, repeat with room), the radix switch, against the
+    oracle and against the two-call path."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77 + len(kind))
+    if kind == "dense":
+        kws = [bytes(rng.integers(97, 123, size=rng.integers(3, 9)).astype(np.uint8)) for _ in range(300)]
+        sym = 1
+        texts = [rng.integers(97, 123, size=1 << 20).astype(np.uint8),          # sparse: a record per few thousand symbols
+                 rng.integers(97, 100, size=200000).astype(np.uint8)]
+        kws += [b"ab", b"abc", b"ca", b"b"]                                     # ... and the second text is full of these
+    elif kind == "gram":
+        kws = [rng.integers(97, 104, size=rng.integers(4, 13)).astype(np.uint8) for _ in range(12000)]
+        sym = 1
+        texts = [rng.integers(96, 105, size=700000).astype(np.uint8), rng.integers(110, 120, size=50000).astype(np.uint8)]
+    else:
+        kws = [rng.integers(0, 400, size=rng.integers(1, 7)).astype(np.uint16) for _ in range(1500)]
+        sym = 2
+        texts = [rng.integers(0, 403, size=300000).astype(np.uint16), rng.integers(0, 60000, size=100000).astype(np.uint16)]
+    m, o = build_pair(kws, sym)
+    plan = m.plan(0)
+    for text in texts:
+        want = o.scan(text)
+        dev = _dev(torch, text)
+        for base in (0, (1 << 41) + 12345):
+            w = want.copy()
+            w["end_pos"] += base
+            got = plan.scan_sorted(dev, pos_base=base, capacity=max(want.size, 1))
+            assert np.array_equal(got, w), (kind, base)
+            assert np.array_equal(plan.scan_sorted(dev, pos_base=base, capacity=max(want.size, 1), fused=False), w)
+        if want.size > 3:       # too small: the total comes back, nothing is claimed about the buffer; then with room
+            rec, cnt, _ = plan.scan_ordered(dev, capacity=want.size // 2)
+            assert int(cnt.item()) == want.size
+            plan.status()
+            assert np.array_equal(plan.scan_sorted(dev, capacity=want.size // 2), want)
+        cut = text.size - 5     # (almost) nothing to report
+        tail = want[want["end_pos"] >= cut]
+        assert np.array_equal(plan.scan_sorted(dev, emit_from=cut, capacity=64), tail)
+        monkeypatch.setenv("ACM_GPU_ORDER", "radix")
+        assert np.array_equal(plan.scan_sorted(dev, capacity=max(want.size, 1) + 100), want)
+        monkeypatch.delenv("ACM_GPU_ORDER")
+    # a text without any match, and one with exactly one
+    blank = np.full(5000, 255 if sym == 1 else 65535, dtype=texts[0].dtype)
+    assert plan.scan_sorted(_dev(torch, blank)).size == 0
+    one = blank.copy()
+    one[1234:1234 + len(kws[0])] = np.frombuffer(kws[0], dtype=np.uint8) if isinstance(kws[0], bytes) else kws[0]
+    assert np.array_equal(plan.scan_sorted(_dev(torch, one)), o.scan(one))
+
+
 def test_dense_matches_everywhere(torch_cuda):
     """Output blow-up: nested keywords matching at every position (queue flush path)."""
     kws = [b"a" * k for k in range(1, 9)] + [b"ab", b"b"]
