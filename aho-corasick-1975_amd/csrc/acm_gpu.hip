@@ -132,6 +132,9 @@ struct EmitCtx {
    * area, from which close_holes_kernel brings them back into the holes below the dense count */
   uint4 *spill;
   uint64_t spill_slots;
+  /* tiled scans (dev_tiles.h): `records` is a raw area of whole chunks, and a wave that reserves
+   * chunk c writes chunk_prev[c] = the chunk it filled before (NONE: its first) */
+  uint32_t *chunk_prev;
 };
 constexpr uint32_t HIT_LEN4 = 0x80000000u;
 /* the hit's word is the keyword itself: id (below 2^28) | length << 28 (1-3; 0: 4 symbols) | HIT_KW -- what
@@ -176,6 +179,7 @@ constexpr uint32_t IT_OUT = 1u << 29;   /* report the outputs of the state itsel
 #include "dev_gram.h"
 #include "dev_misc.h"
 #include "dev_order.h"
+#include "dev_tiles.h"
 
 } // namespace
 
@@ -284,6 +288,11 @@ struct ACMPlan {
    * per wave and the spill area, one chunk of records per wave (64 MB on 256 CUs) */
   void *d_holes = nullptr, *d_spill = nullptr;
   uint32_t direct_regions = 0;
+  /* a tiled scan in progress (acm_gpu_scan_ordered_device -> scan_tiled): the 4-gram kernel writes
+   * a TileEntry per tile from tiled_dir[tiled_base] on and links its chunks in tiled_prev */
+  void *tiled_dir = nullptr; /* TileEntry[] */
+  uint32_t *tiled_prev = nullptr;
+  uint32_t tiled_base = 0;
   uint64_t segment = SEGMENT;
   uint64_t generation = 0; /* for the machine-cached plan */
   /* Dictionary growth without a rebuild (acm_gpu_plan_update): the keywords a machine got after
@@ -391,18 +400,21 @@ starts_fn (bool lut_lds, bool count_only) {
 }
 
 const void *
-gram_kernel_ptr (bool count_only, bool shorts, bool wide) {
+gram_kernel_ptr (bool count_only, bool shorts, bool wide, bool tiled = false) {
+  if (tiled) /* (narrow alphabets, record mode) */
+    return shorts ? reinterpret_cast<const void *> (&scan_gram_kernel<false, true, false, true>)
+                  : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, false, true>);
   if (wide && shorts)
-    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, true, true>)
-                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, true, true>);
+    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, true, true, false>)
+                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, true, true, false>);
   if (wide)
-    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, false, true>)
-                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, true>);
+    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, false, true, false>)
+                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, true, false>);
   if (shorts)
-    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, true, false>)
-                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, true, false>);
-  return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, false, false>)
-                    : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, false>);
+    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, true, false, false>)
+                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, true, false, false>);
+  return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, false, false, false>)
+                    : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, false, false>);
 }
 
 const void *
@@ -1201,6 +1213,9 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     for (int co = 0; co < 2; co++)
       PLAN_TRY (hipFuncSetAttribute (gram_kernel_ptr (co != 0, p->gram_shorts, p->gram_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)p->gram_lds_bytes));
+    if (!p->gram_wide)
+      PLAN_TRY (hipFuncSetAttribute (gram_kernel_ptr (false, p->gram_shorts, false, true), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)p->gram_lds_bytes));
   }
   if (dense && !p->gram) {
     for (int co = 0; co < 2; co++)
@@ -1529,24 +1544,40 @@ launch_starts (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_
   return ACM_GPU_OK;
 }
 
-template <bool COUNT_ONLY>
-int
-launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop, bool first_segment, bool last_segment) {
+/* the tiles of one launch of the 4-gram kernel over a segment of n symbols: R groups of 1,024
+ * symbols each, tiles [begin, end) */
+struct GramTiling {
+  uint32_t R, begin, end;
+};
+GramTiling
+gram_tiling (const ACMPlan *p, uint32_t n, uint32_t emit_from) {
   const uint32_t group = WAVE * 16;
-  const uint32_t ngroups = (uint32_t)(((uint64_t)a.n + group - 1) / group);
-  uint32_t grid = (uint32_t)p->cu_count;
+  const uint32_t ngroups = (uint32_t)(((uint64_t)n + group - 1) / group);
   const uint32_t wpb = SPARSE_THREADS / WAVE;
   const uint32_t back = p->finfo.lmax > 1 ? p->finfo.lmax - 1 : 0;
-  const uint32_t first_group = (a.emit_from > back ? a.emit_from - back : 0) / group;
-  uint64_t R = (ngroups - first_group) / ((uint64_t)grid * wpb * 16);
+  const uint32_t first_group = (emit_from > back ? emit_from - back : 0) / group;
+  uint64_t R = (ngroups - first_group) / ((uint64_t)p->cu_count * wpb * 16);
   if (R < 4)
     R = 4;
   if (R > 64)
     R = 64;
+  GramTiling t;
+  t.R = (uint32_t)R;
+  t.begin = first_group / (uint32_t)R;
+  t.end = (uint32_t)((ngroups + R - 1) / R);
+  return t;
+}
+
+template <bool COUNT_ONLY>
+int
+launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop, bool first_segment, bool last_segment) {
+  uint32_t grid = (uint32_t)p->cu_count;
+  const uint32_t wpb = SPARSE_THREADS / WAVE;
+  const GramTiling T = gram_tiling (p, a.n, a.emit_from);
   GramK K = p->GK;
-  K.R = (uint32_t)R;
-  a.range_begin = first_group / (uint32_t)R;
-  a.range_end = (uint32_t)((ngroups + R - 1) / R);
+  K.R = T.R;
+  a.range_begin = T.begin;
+  a.range_end = T.end;
   const uint32_t tiles = a.range_end - a.range_begin;
   if ((tiles + wpb - 1) / wpb < grid)
     grid = (tiles + wpb - 1) / wpb;
@@ -1564,13 +1595,20 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t 
   uint32_t resume = first_segment ? 0u : 1u;
   if (holes && first_segment)
     HIP_TRY (hipMemsetAsync (holes, 0, (size_t)p->direct_regions * sizeof (RecHole), st));
-  void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill, &holes, &resume };
-  HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts, p->gram_wide), dim3 (grid), dim3 (SPARSE_THREADS), args,
+  /* a tiled scan: a directory entry per tile, the chunks linked, the holes left alone (dev_tiles.h) */
+  TileEntry *dir = (!COUNT_ONLY && direct) ? static_cast<TileEntry *> (p->tiled_dir) : nullptr;
+  uint32_t dir_base = p->tiled_base;
+  if (dir)
+    p->tiled_base += tiles;
+  void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill, &holes, &resume, &dir, &dir_base };
+  HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts, p->gram_wide, dir != nullptr), dim3 (grid), dim3 (SPARSE_THREADS), args,
                             p->gram_lds_bytes, st));
   if (stop)
     HIP_TRY (hipEventRecord (stop, st));
   if (!COUNT_ONLY) {
-    if (direct && last_segment) {
+    if (direct && dir) {
+      /* (nothing: tile_gather_kernel reads the records where they lie) */
+    } else if (direct && last_segment) {
       const uint32_t n_waves = p->direct_regions; /* (an earlier segment may have had more blocks than this one) */
       uint32_t npow = 64;
       while (npow < n_waves)
@@ -2175,7 +2213,8 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   EmitCtx E{};
   E.oinfo = p->d_oinfo;
   E.records = d_records;
-  E.count = shared_total ? shared_total : ((use_dense || accumulate) ? p->d_total : reinterpret_cast<unsigned long long *> (d_count));
+  const bool tiled = !COUNT_ONLY && direct && p->tiled_dir != nullptr;
+  E.count = shared_total ? shared_total : ((use_dense || accumulate || tiled) ? p->d_total : reinterpret_cast<unsigned long long *> (d_count));
   E.capacity = COUNT_ONLY ? 0 : capacity;
   E.wrows = p->d_wrows;
   E.cont_dh = p->d_cont_dh;
@@ -2188,7 +2227,8 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   E.chain = p->d_chain;
   E.chain_base = p->K.HD;
   E.spill = static_cast<uint4 *> (p->d_spill);
-  E.spill_slots = (!COUNT_ONLY && direct) ? (uint64_t)p->direct_regions * REC_CHUNK : 0;
+  E.spill_slots = (!COUNT_ONLY && direct && !tiled) ? (uint64_t)p->direct_regions * REC_CHUNK : 0;
+  E.chunk_prev = tiled ? p->tiled_prev : nullptr;
   E.error = p->d_total ? reinterpret_cast<unsigned int *> (p->d_total) + 3 : nullptr;
 
   /* segments of at most SEGMENT symbols; each restarts from the root `halo` symbols early
@@ -2651,14 +2691,117 @@ acm_gpu_order_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, u
   return order_records (plan, d_records, n, nullptr, pos_lo, span, d_tmp, tmp_bytes, stream);
 }
 
+/* ---- tiled scans (dev_tiles.h): 4-gram plans over narrow alphabets */
+namespace {
+struct TiledPlan {
+  bool ok = false;
+  uint32_t n_tiles = 0;
+  uint64_t raw_slots = 0;
+  uint32_t len_bits = 1, nsub = 2;
+  size_t o_raw = 0, o_prev = 0, o_dir = 0, o_size = 0, o_begin = 0, o_cub = 0, cub_bytes = 0, total = 0;
+};
+
+/* the tiles of all the launches scan_impl makes for this text (the same walk over the segments) */
+TiledPlan
+tiled_layout (const ACMPlan *p, uint64_t capacity, uint64_t n, uint64_t emit_from) {
+  TiledPlan L;
+  const char *env = getenv ("ACM_GPU_ORDER"); /* radix / buckets: not this way (experiments, tests) */
+  if (env && (strcmp (env, "radix") == 0 || strcmp (env, "buckets") == 0))
+    return L;
+  if (!p->gram || p->gram_wide || p->delta || p->finfo.lmax > WAVE * 16 || p->finfo.n_edges == 0)
+    return L;
+  if (n == 0 || emit_from >= n || capacity == 0 || capacity >= (1ull << 31))
+    return L;
+  const uint64_t halo = p->finfo.lmax > 1 ? (((uint64_t)p->finfo.lmax - 1 + 15) / 16) * 16 : 0;
+  const uint64_t SEG = p->segment;
+  uint64_t tiles = 0;
+  for (uint64_t seg = emit_from / SEG * SEG; seg < n; seg += SEG) {
+    const uint64_t seg_end = seg + SEG < n ? seg + SEG : n;
+    const uint64_t read_begin = seg > halo ? seg - halo : 0;
+    const uint64_t ef = emit_from > seg ? emit_from : seg;
+    const GramTiling T = gram_tiling (p, (uint32_t)(seg_end - read_begin), (uint32_t)(ef - read_begin));
+    tiles += T.end - T.begin;
+    if (T.R * (WAVE * 16) / (1u << TILE_BUCKET_LOG2) + 1 > L.nsub)
+      L.nsub = T.R * (WAVE * 16) / (1u << TILE_BUCKET_LOG2) + 1;
+  }
+  if (tiles == 0 || tiles >= (1ull << 30))
+    return L;
+  L.n_tiles = (uint32_t)tiles;
+  /* whole chunks: the records and what every wave may leave unused of its last chunk */
+  L.raw_slots = (capacity + REC_CHUNK - 1) / REC_CHUNK * REC_CHUNK + ((uint64_t)p->cu_count * (SPARSE_THREADS / WAVE) + 1) * REC_CHUNK;
+  while ((1u << L.len_bits) <= p->finfo.lmax)
+    L.len_bits++;
+  size_t cub = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum (nullptr, cub, static_cast<uint32_t *> (nullptr), static_cast<uint32_t *> (nullptr), (int)(L.n_tiles + 1), nullptr);
+  L.cub_bytes = cub;
+  size_t cur = 0;
+  L.o_raw = blob_reserve (cur, L.raw_slots * sizeof (ACMRecord));
+  L.o_prev = blob_reserve (cur, (L.raw_slots / REC_CHUNK) * 4);
+  L.o_dir = blob_reserve (cur, (size_t)L.n_tiles * sizeof (TileEntry));
+  L.o_size = blob_reserve (cur, ((size_t)L.n_tiles + 1) * 4);
+  L.o_begin = blob_reserve (cur, ((size_t)L.n_tiles + 1) * 4);
+  L.o_cub = blob_reserve (cur, cub + 16);
+  L.total = cur + 256;
+  L.ok = true;
+  return L;
+}
+
+int
+scan_tiled (ACMPlan *plan, const TiledPlan &L, const void *d_text, uint64_t n_symbols, uint64_t emit_from, uint64_t pos_base, ACMRecord *d_records,
+            uint64_t capacity, uint64_t *d_count, void *d_tmp, hipStream_t st) {
+  HIP_TRY (hipSetDevice (plan->device));
+  unsigned char *t = static_cast<unsigned char *> (d_tmp);
+  plan->tiled_dir = t + L.o_dir;
+  plan->tiled_prev = reinterpret_cast<uint32_t *> (t + L.o_prev);
+  plan->tiled_base = 0;
+  int rc = scan_impl<false> (plan, d_text, n_symbols, emit_from, pos_base, reinterpret_cast<ACMRecord *> (t + L.o_raw), L.raw_slots, d_count, st);
+  const uint32_t written = plan->tiled_base;
+  plan->tiled_dir = nullptr;
+  plan->tiled_prev = nullptr;
+  plan->tiled_base = 0;
+  if (rc || written != L.n_tiles) {
+    (void)hipMemsetAsync (plan->d_total, 0, 8, st); /* (the scan's running total must not leak into the next one) */
+    return rc ? rc : ACM_GPU_E_INTERNAL;
+  }
+  TileK K{};
+  K.raw = reinterpret_cast<const ACMRecord *> (t + L.o_raw);
+  K.chunk_prev = reinterpret_cast<const uint32_t *> (t + L.o_prev);
+  K.dir = reinterpret_cast<const TileEntry *> (t + L.o_dir);
+  K.n_tiles = L.n_tiles;
+  K.size = reinterpret_cast<uint32_t *> (t + L.o_size);
+  K.begin = reinterpret_cast<const uint32_t *> (t + L.o_begin);
+  K.out = d_records;
+  K.capacity = capacity;
+  K.d_count = reinterpret_cast<unsigned long long *> (d_count);
+  K.reserved = plan->d_total;
+  K.len_bits = L.len_bits;
+  K.nsub = L.nsub;
+  K.error = reinterpret_cast<unsigned int *> (plan->d_total) + 3;
+  const uint32_t sblocks = (L.n_tiles + 1 + 3) / 4;
+  hipLaunchKernelGGL (tile_size_kernel, dim3 (sblocks < (uint32_t)plan->cu_count * 16 ? sblocks : (uint32_t)plan->cu_count * 16), dim3 (256), 0, st, K);
+  HIP_TRY (hipGetLastError ());
+  size_t cub = L.cub_bytes;
+  HIP_TRY (hipcub::DeviceScan::ExclusiveSum (t + L.o_cub, cub, K.size, reinterpret_cast<uint32_t *> (t + L.o_begin), (int)(L.n_tiles + 1), st));
+  const uint32_t gblocks = L.n_tiles < (uint32_t)plan->cu_count * 16 ? L.n_tiles : (uint32_t)plan->cu_count * 16;
+  hipLaunchKernelGGL (tile_gather_kernel, dim3 (gblocks), dim3 (TILE_THREADS), tile_lds_bytes (L.nsub), st, K);
+  HIP_TRY (hipGetLastError ());
+  return ACM_GPU_OK;
+}
+} // namespace
+
 /* Scan and canonical order in one call, nothing but kernel launches on `stream`: the order passes
  * take the number of records from *d_count on the device.  A scan that overflows `capacity` leaves
  * the total in *d_count as acm_gpu_scan_device does and nothing in order (the caller repeats it with
- * room).  Record sets the bucket passes do not take (2^31 records or more, positions past 2^63 /
+ * room).  4-gram plans over narrow alphabets scan in tiles and order in one pass (dev_tiles.h).
+ * Record sets the bucket passes do not take (2^31 records or more, positions past 2^63 /
  * lengths): the count comes to the host and acm_gpu_order_records_device's fallback runs. */
 extern "C" size_t
 acm_gpu_scan_ordered_tmp_bytes (const ACMPlan *plan, uint64_t capacity, uint64_t n_symbols) {
-  return acm_gpu_order_tmp_bytes (plan, capacity, n_symbols);
+  if (!plan)
+    return 0;
+  const size_t general = acm_gpu_order_tmp_bytes (plan, capacity, n_symbols);
+  const TiledPlan L = tiled_layout (plan, capacity, n_symbols, 0); /* (emit_from = 0: the most tiles) */
+  return L.ok && L.total > general ? L.total : general;
 }
 
 extern "C" int
@@ -2668,6 +2811,9 @@ acm_gpu_scan_ordered_device (ACMPlan *plan, const void *d_text, uint64_t n_symbo
     return ACM_GPU_E_ARG;
   if (capacity && tmp_bytes < acm_gpu_scan_ordered_tmp_bytes (plan, capacity, n_symbols))
     return ACM_GPU_E_ARG;
+  const TiledPlan T = tiled_layout (plan, capacity, n_symbols, emit_from);
+  if (T.ok)
+    return scan_tiled (plan, T, d_text, n_symbols, emit_from, pos_base, d_records, capacity, d_count, d_tmp, static_cast<hipStream_t> (stream));
   int rc = acm_gpu_scan_device (plan, d_text, n_symbols, emit_from, pos_base, d_records, capacity, d_count, stream);
   if (rc || capacity == 0 || n_symbols == 0)
     return rc;

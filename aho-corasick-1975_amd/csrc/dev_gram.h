@@ -127,10 +127,10 @@ gram_item_word (const uint32_t (&c)[20], int j, uint32_t idx) {
   return lshl_or (j + 5 < 20 ? c[j + 5] : GRAM_CLS_UNKNOWN, 25u, y);
 }
 
-template <bool COUNT_ONLY, bool SHORTS, bool WIDE>
+template <bool COUNT_ONLY, bool SHORTS, bool WIDE, bool TILED>
 __global__ __launch_bounds__ (SPARSE_THREADS) void
 scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
-                  uint32_t *fill, RecHole *holes, uint32_t resume) {
+                  uint32_t *fill, RecHole *holes, uint32_t resume, TileEntry *dir, uint32_t dir_base) {
   extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
   constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
   constexpr uint32_t GROUP = WAVE * 16;
@@ -199,8 +199,12 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
         w0.limit = (below || above) ? REC_CHUNK : 0u;
         w0.have = 1;
         w0.pad[0] = REC_CHUNK - h.len; /* slots used */
+        w0.pad[1] = 1;
+        w0.prev1 = w0.prev2 = NONE;
       }
     }
+    if (!w0.have)
+      w0.prev1 = w0.prev2 = NONE;
     Ws[wib] = w0;
   }
   const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
@@ -712,15 +716,70 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
     }
   };
 
+  /* tiled scan: the wave's stream index = records it has written so far (up to a constant) */
+  static_assert (!TILED || (!WIDE && !COUNT_ONLY), "tiled scans write their records themselves");
+  constexpr bool tiled = TILED; /* (an instantiation of its own: the loop below with the drain inside it costs the plain scan registers) */
+  auto stream_index = [&] (const WaveRec &w) -> uint32_t { return w.have ? (w.pad[1] - 1u) * REC_CHUNK + (uint32_t)counted : 0u; };
+  if (tiled && lane == 0)
+    Ws[wib].tile = NONE;
+  /* the queues and the pipeline are emptied: when the text is through, and in a tiled scan behind
+   * every tile (all its records are then written, side by side) */
+  auto drain = [&] () {
+#if ACM_GRAM_PUSH2
+      if (!WIDE)
+        qn1 = uniform (fill1);
+#endif
+      if (qn1)
+        batch_step (qn1);
+#if ACM_GRAM_PUSH2
+      fill1 = 0;
+      asm volatile ("" : "+v"(fill1));
+#endif
+#pragma unroll
+      for (int d = 0; d < GRAM_DEPTH; d++)
+        consume_oldest ();
+      while (qn2)
+        walk_batch (qn2 < WAVE ? qn2 : WAVE);
+      if (SHORTS && qn3)
+        short_batch (qn3);
+  };
   for (;;) {
     const uint32_t tile = share.next (next_tile, lane);
+    if (tiled) {
+      drain ();
+      if (lane == 0) {
+        const WaveRec w = Ws[wib];
+        if (w.tile != NONE) {
+          const uint32_t s_end = stream_index (w), cur_tile = w.tile;
+          const uint32_t tile_begin = cur_tile * K.R * GROUP, tile_len = K.R * GROUP;
+          const uint32_t tile_end = A.n - tile_begin < tile_len ? A.n : tile_begin + tile_len;
+          TileEntry e;
+          e.end_slot = w.have ? (((unsigned long long)w.base_hi << 32) | w.base_lo) + (uint32_t)counted : 0ull;
+          e.lo = E.pos_base + (tile_begin > E.emit_from ? tile_begin : E.emit_from);
+          e.hi = E.pos_base + tile_end;
+          e.n = s_end - w.s_begin;
+          e.n_late = s_end - w.s_late;
+          e.c1 = w.prev1;
+          e.c2 = w.prev1 != NONE ? w.prev2 : NONE;
+          e.pad[0] = e.pad[1] = 0;
+          dir[dir_base + (cur_tile - A.range_begin)] = e;
+        }
+      }
+    }
     if (tile == NONE)
       break;
     DIAG (d_tiles++;)
+    if (tiled && lane == 0) {
+      WaveRec *W = Ws + wib;
+      W->tile = tile;
+      W->s_begin = W->s_late = stream_index (*W);
+    }
     const uint32_t g0 = tile * K.R;
     uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
     for (uint32_t k = 0; k < K.R; k++) {
       uint4 n3;
+      if (tiled && k + 1 == K.R && lane == 0) /* (keywords are no longer than a group here: what ends beyond the tile starts in its last group) */
+        Ws[wib].s_late = stream_index (Ws[wib]);
       walk_group (c0, c1.x, g0 + k, n3);
       c0 = c1;
       c1 = c2;
@@ -728,19 +787,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       c3 = n3;
     }
   }
-#if ACM_GRAM_PUSH2
-  if (!WIDE)
-    qn1 = uniform (fill1);
-#endif
-  if (qn1)
-    batch_step (qn1);
-#pragma unroll
-  for (int d = 0; d < GRAM_DEPTH; d++)
-    consume_oldest ();
-  while (qn2)
-    walk_batch (qn2 < WAVE ? qn2 : WAVE);
-  if (SHORTS && qn3)
-    short_batch (qn3);
+  if (!tiled)
+    drain ();
   if (COUNT_ONLY) {
     const uint32_t incl = wave_incl_scan ((uint32_t)counted);
     const uint32_t total = __shfl (incl, WAVE - 1, WAVE);

@@ -203,6 +203,25 @@ struct WaveRec {
   uint32_t base_lo, base_hi; /* index of that slot */
   uint32_t limit;            /* REC_CHUNK for a chunk that lies entirely on one side of the capacity, else 0: slow path only */
   uint32_t have;             /* a chunk has been reserved */
+  uint32_t pad[2];           /* [0] resumed scans: slots used of the chunk that is carried over; [1] chunks reserved so far */
+  /* tiled scans: the tile at hand, the wave's stream index (records written so far, up to a
+   * constant) when it began and when its last group began -- kept here, not in registers: the
+   * scan kernel has none to spare */
+  uint32_t tile, s_begin, s_late;
+  uint32_t prev1, prev2;     /* the two chunks filled before the current one (NONE: not known) */
+  uint32_t pad2;
+};
+/* A tiled scan (the 4-gram kernel with a directory: acm_gpu_scan_ordered_device) empties its
+ * queues at the end of every tile, so that the records of a tile lie side by side in the wave's
+ * stream of chunks, and says where: the slot behind the tile's last record, how many records, how
+ * many of them were written after the tile's last group began (those that END beyond the tile --
+ * they belong to the next tile's stretch of the output -- are among these), and the range of end
+ * positions the tile owns. */
+struct TileEntry {
+  uint64_t end_slot;
+  uint64_t lo, hi;
+  uint32_t n, n_late;
+  uint32_t c1, c2;           /* the chunks in front of end_slot's (NONE: follow chunk_prev) -- most tiles end within three */
   uint32_t pad[2];
 };
 struct RecHole {
@@ -258,7 +277,15 @@ emit_records_slow (const EmitCtx *Ep, WaveRec *W, uint32_t used, bool hit, uint3
     W->base_lo = (uint32_t)nb;
     W->base_hi = (uint32_t)(nb >> 32);
     W->limit = (below || above) ? REC_CHUNK : 0u;
+    if (E.chunk_prev) {
+      const uint32_t was = W->have ? (uint32_t)(base / REC_CHUNK) : NONE;
+      if (below)
+        E.chunk_prev[nb / REC_CHUNK] = was;
+      W->prev2 = W->prev1;
+      W->prev1 = was;
+    }
     W->have = 1;
+    W->pad[1]++; /* chunks reserved so far (a tiled scan's stream index: TileEntry) */
   }
   return total - room;
 }
