@@ -293,6 +293,7 @@ struct ACMPlan {
   void *tiled_dir = nullptr; /* TileEntry[] */
   uint32_t *tiled_prev = nullptr;
   uint32_t tiled_base = 0;
+
   uint64_t segment = SEGMENT;
   uint64_t generation = 0; /* for the machine-cached plan */
   /* Dictionary growth without a rebuild (acm_gpu_plan_update): the keywords a machine got after
@@ -2615,6 +2616,13 @@ acm_gpu_order_tmp_bytes (const ACMPlan *plan, uint64_t n, uint64_t span) {
 }
 
 namespace {
+/* what is cleared in front of pass A: the counts and cur[0] -- rounded up to whole 256 bytes (one
+ * fill kernel instead of a body and a tail; what lies behind is the sums' own space) */
+size_t
+order_zero_bytes (const OrderPlan &L) {
+  return (((size_t)L.n_buckets + 2) * 4 + 255) & ~(size_t)255;
+}
+
 /* n_dev == nullptr: n records.  Else: the record count is the scan's, in device memory, and n the
  * capacity of d_records (OrderK::n_dev) -- nothing here waits for the host. */
 bool
@@ -2655,9 +2663,9 @@ order_records (ACMPlan *plan, ACMRecord *d_records, uint64_t n, const unsigned l
    * prefix sums -- where each bucket begins, the cursors pass B advances; when it is done cur[1 + b]
    * is where bucket b ENDS, so that P = cur reads P[b] = begin, P[b + 1] = end for pass C (no copy
    * of the sums is kept) */
-  HIP_TRY (hipMemsetAsync (hist, 0, ((size_t)L.n_buckets + 2) * 4, st)); /* (the counts and cur[0], which lies right behind them) */
   const uint64_t pieces = (n + ORDER_PIECE - 1) / ORDER_PIECE, pblocks = (pieces + ORDER_THREADS / WAVE - 1) / (ORDER_THREADS / WAVE);
   const uint32_t grid = (uint32_t)(pblocks < (uint64_t)plan->cu_count * 8 ? pblocks : (uint64_t)plan->cu_count * 8);
+  HIP_TRY (hipMemsetAsync (hist, 0, order_zero_bytes (L), st)); /* (the counts and cur[0], which lies right behind them) */
   hipLaunchKernelGGL (order_bucket_kernel<false>, dim3 (grid), dim3 (ORDER_THREADS), 0, st, K, hist, static_cast<ACMRecord *> (nullptr));
   HIP_TRY (hipGetLastError ());
   size_t cub = L.cub_bytes;
@@ -2814,10 +2822,10 @@ acm_gpu_scan_ordered_device (ACMPlan *plan, const void *d_text, uint64_t n_symbo
   const TiledPlan T = tiled_layout (plan, capacity, n_symbols, emit_from);
   if (T.ok)
     return scan_tiled (plan, T, d_text, n_symbols, emit_from, pos_base, d_records, capacity, d_count, d_tmp, static_cast<hipStream_t> (stream));
+  const OrderPlan L = order_layout (plan, capacity, n_symbols);
   int rc = acm_gpu_scan_device (plan, d_text, n_symbols, emit_from, pos_base, d_records, capacity, d_count, stream);
   if (rc || capacity == 0 || n_symbols == 0)
     return rc;
-  const OrderPlan L = order_layout (plan, capacity, n_symbols);
   if (order_by_buckets (plan, L))
     return order_records (plan, d_records, capacity, reinterpret_cast<const unsigned long long *> (d_count), pos_base, n_symbols, d_tmp, tmp_bytes, stream);
   uint64_t found = 0;

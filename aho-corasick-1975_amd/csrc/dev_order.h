@@ -35,6 +35,8 @@ struct OrderK {
   uint64_t span;
   uint32_t mode;
 };
+/* (counting the buckets in the dense kernel's put_outputs instead of pass A -- one atomic per record
+ * where the record is written -- cost the scan kernel 277 -> 396 us on config 2: measured, not kept) */
 
 __device__ __forceinline__ uint64_t
 order_n (const OrderK &K) {
@@ -70,6 +72,12 @@ order_bucket_kernel (OrderK K, uint32_t *hist, ACMRecord *out) {
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves = (uint64_t)gridDim.x * blockDim.x / WAVE;
   const uint64_t n = order_n (K);
+  if (SCATTER && n && hist[K.n_buckets] != n) {
+    /* the buckets' counts do not add up to the records (never expected): nothing is moved */
+    if (K.error && threadIdx.x == 0)
+      *K.error = 1;
+    return;
+  }
   const uint64_t pieces = (n + ORDER_PIECE - 1) / ORDER_PIECE;
   for (uint64_t piece = wave; piece < pieces; piece += waves) {
     const uint64_t first = piece * ORDER_PIECE;
@@ -297,6 +305,40 @@ order_first_bucket_at (const uint32_t *__restrict__ P, uint32_t n_buckets, uint6
   }
   return lo;
 }
+/* both ends of a window in one go: the two searches' loads travel together (three round trips, not six) */
+__device__ __forceinline__ void
+order_window_bounds (const uint32_t *__restrict__ P, uint32_t n_buckets, uint64_t want0, uint64_t want1, uint32_t lane, uint32_t &b0, uint32_t &b1) {
+  uint32_t lo0 = 0, hi0 = n_buckets, lo1 = 0, hi1 = n_buckets;
+  while (lo0 < hi0 || lo1 < hi1) {
+    const uint32_t step0 = (hi0 - lo0 + WAVE - 1) / WAVE, step1 = (hi1 - lo1 + WAVE - 1) / WAVE;
+    const uint64_t idx0 = (uint64_t)lo0 + (uint64_t)lane * step0, idx1 = (uint64_t)lo1 + (uint64_t)lane * step1;
+    const uint32_t p0 = idx0 < hi0 ? P[idx0] : 0xFFFFFFFFu, p1 = idx1 < hi1 ? P[idx1] : 0xFFFFFFFFu;
+    const uint32_t c0 = (uint32_t)__popcll (__ballot (idx0 < hi0 && p0 < want0)), c1 = (uint32_t)__popcll (__ballot (idx1 < hi1 && p1 < want1));
+    if (lo0 < hi0) {
+      if (c0 == 0)
+        hi0 = lo0;
+      else {
+        const uint64_t first_not = (uint64_t)lo0 + (uint64_t)c0 * step0;
+        lo0 = lo0 + (c0 - 1) * step0 + 1;
+        if (first_not < hi0)
+          hi0 = (uint32_t)first_not;
+      }
+    }
+    if (lo1 < hi1) {
+      if (c1 == 0)
+        hi1 = lo1;
+      else {
+        const uint64_t first_not = (uint64_t)lo1 + (uint64_t)c1 * step1;
+        lo1 = lo1 + (c1 - 1) * step1 + 1;
+        if (first_not < hi1)
+          hi1 = (uint32_t)first_not;
+      }
+    }
+  }
+  b0 = lo0;
+  b1 = lo1;
+}
+
 __device__ __forceinline__ void
 order_window_role (const OrderK &K, const uint32_t *__restrict__ P, const ACMRecord *__restrict__ bucketed, ACMRecord *__restrict__ out, uint32_t blk,
                    uint32_t nblk) {
@@ -307,7 +349,8 @@ order_window_role (const OrderK &K, const uint32_t *__restrict__ P, const ACMRec
     return; /* order_small_kernel's */
   const uint64_t windows = (n + ORDER_WINDOW - 1) / ORDER_WINDOW;
   for (uint64_t k = wave; k < windows; k += waves) {
-    const uint32_t b0 = order_first_bucket_at (P, K.n_buckets, k * ORDER_WINDOW, lane), b1 = order_first_bucket_at (P, K.n_buckets, (k + 1) * ORDER_WINDOW, lane);
+    uint32_t b0, b1;
+    order_window_bounds (P, K.n_buckets, k * ORDER_WINDOW, (k + 1) * ORDER_WINDOW, lane, b0, b1);
     if (b1 <= b0)
       continue;
     const uint32_t base = uniform (P[b0]), cnt = uniform (P[b1]) - base;

@@ -243,8 +243,13 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
         if gathered is not None:
             assert gathered.shape[0] == total_matches, (gathered.shape[0], total_matches)
             g = gathered.to(dev)
-            if g.shape[0] > 1:
-                assert bool((g[1:, 0] >= g[:-1, 0]).all().item()), "gathered records not in canonical order"
+            if g.shape[0] > 1:     # canonical order: end_pos ascending, at one end_pos the longer match first
+                ln = g[:, 1] & 0xFFFFFFFF
+                ok = (g[1:, 0] > g[:-1, 0]) | ((g[1:, 0] == g[:-1, 0]) & (ln[1:] < ln[:-1]))
+                assert bool(ok.all().item()), "gathered records not in canonical order"
+                del ln, ok
+            if world == 1:         # ... and the same record set as the unordered scan's (whose digest the oracle's known answer pins)
+                assert acm.synth.device_digest(g, g.shape[0]) == (full_count, full_digest), "ordered records differ from the scan's record set"
             del g
         # a step is one launch of the scan kernel per segment of 2^31 symbols (16 GiB: 8 launches)
         launches_per_step = max(kern_launches // max(steps, 1), 1)

@@ -611,6 +611,17 @@ def _scan_whole_vs_shards(torch, plan, text, n, lmax, cap, shards=4, known=None)
             assert got == (mk["count"], int(mk["digest"], 16)), (mk, got)
     whole = _checksums(torch, rec, whole_n)
     assert int(plan.count(text, n).item()) == whole_n
+    # the same text through acm_gpu_scan_ordered_device (4-gram plans: a tiled scan and ONE ordering
+    # pass; the others: the bucket passes): the same record set, in canonical order
+    rec2, cnt2, tmp = plan.scan_ordered(text, n, capacity=whole_n + 1000)
+    assert int(cnt2.item()) == whole_n
+    plan.status()
+    assert _checksums(torch, rec2, whole_n) == whole
+    ln = rec2[:whole_n, 1] & 0xFFFFFFFF
+    ok = (rec2[1:whole_n, 0] > rec2[:whole_n - 1, 0]) | ((rec2[1:whole_n, 0] == rec2[:whole_n - 1, 0]) & (ln[1:] < ln[:-1]))
+    assert bool(ok.all().item()), "acm_gpu_scan_ordered_device: records not in canonical order"
+    del rec2, cnt2, tmp, ln, ok
+    torch.cuda.empty_cache()
     tot, sums = 0, [0, 0, 0, 0]
     for r in range(shards):
         rb, b, e = acm.sharded.shard_bounds(n, r, shards, lmax)
