@@ -71,16 +71,11 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
 constexpr int QCAP = 128;           /* per-wave queue of (position, state) items, 8 B each */
 constexpr uint32_t GRAM_Q2 = 96;    /* 4-gram kernel: per-wave queue of walk candidates */
-/* 4-gram kernel: its first queue.  -DACM_GRAM_PUSH2=1 (experiment, measured 9.6 % SLOWER: 2.425
- * against 2.213 ms per 2 GiB of config 3) builds the branch-free push of dev_gram.h, whose queue
- * holds 63 waiting + 2 x 64 pushed items; the product is built without it */
-#ifndef ACM_GRAM_PUSH4
-#define ACM_GRAM_PUSH4 0
-#endif
-#ifndef ACM_GRAM_PUSH2
-#define ACM_GRAM_PUSH2 0
-#endif
-constexpr uint32_t GRAM_Q1 = ACM_GRAM_PUSH2 ? 192 : 128;
+/* 4-gram kernel: its first queue (63 items waiting + up to 64 from one position).  Two other forms
+ * of the push -- the fill in a vector register with the exec mask narrowed around the LDS write
+ * (9.6 % slower), four positions' compares ahead of their scalar counts (19 % slower: 217 scalar
+ * and 115 vector registers spilled) -- are tools/experiments/r03_gram_push_variants.patch */
+constexpr uint32_t GRAM_Q1 = 128;
 constexpr uint32_t GRAM_NO_PEEK = 0xFFFFFFFFu; /* 4-gram kernel, GramK::g5peek: the state's record has to be looked at */
 constexpr int DENSE_THREADS = 1024; /* one workgroup per CU, 16 waves */
 /* dense kernel geometry: C = 64 bytes per lane-stream per tile, S = 2 streams per lane
@@ -3066,9 +3061,17 @@ multi_scan (ACMMulti *mu, const void *const *d_text, uint64_t n, ACMRecord *d_ou
         s.cap = s.found;
         MULTI_TRY (hipMalloc (reinterpret_cast<void **> (&s.rec), s.cap * sizeof (ACMRecord)));
       }
-      /* (shards of one device share its stream: their scans run one after the other) */
+      /* (shards of one device share its stream: their scans run one after the other.)  Scan and
+       * canonical order in one call: nothing waits for the host between them, and 4-gram plans scan
+       * in tiles and order in one pass */
       if (s.e > s.b) {
-        rc = scan_plan<false> (mu->plan[s.slot], d_text[r], s.e - s.rb, s.b - s.rb, s.rb, s.rec, s.cap, s.cnt, mu->stream[s.slot]);
+        if (s.tmp) {
+          MULTI_TRY (hipFree (s.tmp));
+          s.tmp = nullptr;
+        }
+        const size_t tb = acm_gpu_scan_ordered_tmp_bytes (mu->plan[s.slot], s.cap, s.e - s.rb);
+        MULTI_TRY (hipMalloc (&s.tmp, tb));
+        rc = acm_gpu_scan_ordered_device (mu->plan[s.slot], d_text[r], s.e - s.rb, s.b - s.rb, s.rb, s.rec, s.cap, s.cnt, s.tmp, tb, mu->stream[s.slot]);
         if (rc) {
           cleanup ();
           return rc;
@@ -3092,21 +3095,12 @@ multi_scan (ACMMulti *mu, const void *const *d_text, uint64_t n, ACMRecord *d_ou
     cleanup ();
     return ACM_GPU_E_OVERFLOW;
   }
-  /* canonical order where the records are, then each shard's run into its place on devices[0] */
+  /* (every shard's records are in canonical order where they are:) each shard's run into its place on devices[0] */
   uint64_t off = 0;
   for (size_t r = 0; r < R; r++) {
     Shard &s = sh[r];
     MULTI_TRY (hipSetDevice (mu->dev[r]));
     hipStream_t st = mu->stream[s.slot];
-    if (s.found > 1) {
-      const size_t tb = acm_gpu_order_tmp_bytes (mu->plan[s.slot], s.found, s.e - s.b);
-      MULTI_TRY (hipMalloc (&s.tmp, tb));
-      rc = acm_gpu_order_records_device (mu->plan[s.slot], s.rec, s.found, s.b, s.e - s.b, s.tmp, tb, st);
-      if (rc) {
-        cleanup ();
-        return rc;
-      }
-    }
     if (s.found) {
       if (mu->dev[r] == mu->dev[0])
         MULTI_TRY (hipMemcpyAsync (d_out + off, s.rec, s.found * sizeof (ACMRecord), hipMemcpyDeviceToDevice, st));

@@ -214,11 +214,6 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   const TileShare share (A);
   const uint32_t last_blk = (A.n - 1) / 16;
   uint32_t qn1 = 0, qn2 = 0, qn3 = 0;
-#if ACM_GRAM_PUSH2
-  uint32_t fill1 = 0; /* narrow alphabets: the first queue's fill as the pushes keep it, in a vector register */
-  asm volatile ("" : "+v"(fill1));
-  const uint32_t q1_lds = (uint32_t)(uintptr_t)(K.queue_off + wib * GRAM_Q1 * 8u); /* LDS address of this wave's first queue (LDS starts at 0: no static LDS here) */
-#endif
   unsigned long long counted = 0;
   RecState rs = { 0ull, 0u }; /* DIRECT: the wave's chunk of records (none yet, or the one a resumed scan left) */
   if (DIRECT && !COUNT_ONLY && resume) {
@@ -609,90 +604,6 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           }
         }
       }
-#if ACM_GRAM_PUSH2
-      /* The push of a position's survivors, without a branch and without the scalar unit in its
-       * way: a wave issues one instruction per ~5 cycles whatever its kind, and a scalar
-       * instruction that reads what a vector compare has just written (the ballot -> branch ->
-       * exec mask -> count -> branch tail of round 2, at every position) waits ~35 cycles for it.
-       * Here the queue's fill stays in a vector register (the same value in every lane): slot =
-       * fill + survivors in the lanes below (v_mbcnt seeded with the fill), fill += survivors
-       * (v_bcnt), and the only scalar instructions are the two that narrow the exec mask around
-       * the LDS write -- seven vector instructions after the compare whose mask they read.  The
-       * fill is looked at after every second position (the queue holds 63 + 2 x 64 items). */
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const bool push = __builtin_amdgcn_ubfe (word[j], ix[j], 1u) != 0; /* v_bfe_u32 (it takes the low 5 bits of the offset itself) */
-        const uint64_t m = __ballot (push);
-        const uint32_t slot = __builtin_amdgcn_mbcnt_hi ((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo ((uint32_t)m, fill1));
-        asm ("v_bcnt_u32_b32 %0, %1, %0" : "+v"(fill1) : "s"((uint32_t)m));
-        asm ("v_bcnt_u32_b32 %0, %1, %0" : "+v"(fill1) : "s"((uint32_t)(m >> 32)));
-        const uint32_t addr = q1_lds + slot * 8u;
-        const uint64_t item = ((uint64_t)gram_item_word (c, 8 * h + j, ix[j]) << 32) | (pos0 + 8 * h + j);
-        uint64_t saved;
-        asm volatile ("s_and_saveexec_b64 %0, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0"
-                      : "=&s"(saved)
-                      : "s"(m), "v"(addr), "v"(item)
-                      : "memory");
-        if (j & 1) {
-          qn1 = uniform (fill1);
-          if (__builtin_expect (qn1 >= WAVE, 0)) {
-            DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)
-            batch_step (WAVE);
-            fill1 = qn1;
-            asm volatile ("" : "+v"(fill1));
-            DIAG (d_cons += __builtin_readcyclecounter () - d_c1; d_b1++;)
-          }
-        }
-      }
-#elif ACM_GRAM_PUSH4
-      /* Four positions' survivors at a time: the four compares first, then the scalar unit's
-       * counts and running sums in one go, then four masked writes.  Position by position, every
-       * push was a chain vector compare -> scalar branch -> exec mask -> write -> scalar count ->
-       * add -> compare -> branch that a wave cannot overlap with anything (a scalar instruction
-       * that reads what a vector compare has just written waits ~35 cycles for it): the ablation
-       * builds price it at 0.42 of the kernel's 1.9 ms per 2 GiB, more than the classes, indices
-       * and table look-ups of all positions together.  If the four might overflow the queue (63
-       * waiting + 4 x 64 in the worst case; ~50 come on config 3) they go one by one. */
-#pragma unroll
-      for (int quad = 0; quad < 2; quad++) {
-        bool push[4];
-        uint64_t m[4];
-        uint32_t at[5];
-        at[0] = qn1;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          push[j] = __builtin_amdgcn_ubfe (word[4 * quad + j], ix[4 * quad + j], 1u) != 0;
-          m[j] = __ballot (push[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          at[j + 1] = at[j] + (uint32_t)__popcll (m[j]);
-        if (__builtin_expect (at[4] <= GRAM_Q1, 1)) {
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (push[j])
-              q1[__builtin_amdgcn_mbcnt_hi ((uint32_t)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo ((uint32_t)m[j], at[j]))] =
-                  make_uint2 (pos0 + 8 * h + 4 * quad + j, gram_item_word (c, 8 * h + 4 * quad + j, ix[4 * quad + j]));
-          qn1 = uniform (at[4]);
-          while (__builtin_expect (qn1 >= WAVE, 0)) {
-            DIAG (const unsigned long long d_c1 = __builtin_readcyclecounter ();)
-            batch_step (WAVE);
-            DIAG (d_cons += __builtin_readcyclecounter () - d_c1; d_b1++;)
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (m[j]) {
-              if (push[j])
-                q1[qn1 + rank_below (m[j])] = make_uint2 (pos0 + 8 * h + 4 * quad + j, gram_item_word (c, 8 * h + 4 * quad + j, ix[4 * quad + j]));
-              qn1 = uniform (qn1 + (uint32_t)__popcll (m[j]));
-              if (qn1 >= WAVE)
-                batch_step (WAVE);
-            }
-          }
-        }
-      }
-#else
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const bool push = __builtin_amdgcn_ubfe (word[j], ix[j], 1u) != 0; /* v_bfe_u32 (it takes the low 5 bits of the offset itself) */
@@ -712,7 +623,6 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
           }
         }
       }
-#endif
     }
   };
 
@@ -725,16 +635,8 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   /* the queues and the pipeline are emptied: when the text is through, and in a tiled scan behind
    * every tile (all its records are then written, side by side) */
   auto drain = [&] () {
-#if ACM_GRAM_PUSH2
-      if (!WIDE)
-        qn1 = uniform (fill1);
-#endif
       if (qn1)
         batch_step (qn1);
-#if ACM_GRAM_PUSH2
-      fill1 = 0;
-      asm volatile ("" : "+v"(fill1));
-#endif
 #pragma unroll
       for (int d = 0; d < GRAM_DEPTH; d++)
         consume_oldest ();

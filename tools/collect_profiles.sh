@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh <tag> [bench.py arguments, e.g. --config 3 --steps 3 --warmup 1]
 # Writes under gpurun_out/profile_<tag>/; copy what should be judged into profiles/.
 set -e
-R=${1:-r02}
+R=${1:-r03}
 shift || true
 ARGS="$@"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$R
@@ -20,12 +20,14 @@ python3 - <<PY
 import csv, glob, collections, json
 out = {"command": "bench.py $ARGS"}
 f = glob.glob("$OUT/trace/*/*kernel_stats.csv")[0]
-out["kernel_stats"] = [dict(name=r["Name"][:110], calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), pct=float(r["Percentage"])) for r in csv.DictReader(open(f))][:8]
+out["kernel_stats"] = [dict(name=r["Name"][:110], calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), pct=float(r["Percentage"])) for r in csv.DictReader(open(f))][:14]
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/pmc_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        k = next((x for x in ("scan_dense_kernel", "scan_gram_kernel", "scan_starts_kernel", "expand_items", "expand_hits", "close_holes") if x in n), None)
+        k = next((x for x in ("scan_dense_kernel", "scan_gram_kernel", "scan_starts_kernel", "expand_items", "expand_hits", "close_holes", "tile_gather", "tile_size", "order_bucket", "order_finish") if x in n), None)
+        if k == "scan_gram_kernel" and n.split("(")[0].rstrip().endswith(", true>"):
+            k = "scan_gram_kernel_tiled"   # (the e2e leg's scan: acm_gpu_scan_ordered_device)
         # record-mode instantiations only (the count-only pass that sizes the record buffer is another kernel)
         count_only = ("scan_gram_kernel<true" in n or
                       (("scan_dense_kernel" in n or "scan_starts_kernel" in n) and ", true>(" in n))
