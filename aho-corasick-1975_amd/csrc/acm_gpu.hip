@@ -76,12 +76,6 @@ constexpr uint32_t GRAM_Q2 = 96;    /* 4-gram kernel: per-wave queue of walk can
  * (9.6 % slower), four positions' compares ahead of their scalar counts (19 % slower: 217 scalar
  * and 115 vector registers spilled) -- are tools/experiments/r03_gram_push_variants.patch */
 constexpr uint32_t GRAM_Q1 = 128;
-/* narrow alphabets: the survivors of the Bloom filters, queued again for the second stage proper
- * (dev_gram.h: light_step / heavy_step); -DACM_GRAM_TWO_LEVEL=0 builds the one-level form */
-#ifndef ACM_GRAM_TWO_LEVEL
-#define ACM_GRAM_TWO_LEVEL 1
-#endif
-constexpr uint32_t GRAM_Q1B = 96;
 constexpr uint32_t GRAM_NO_PEEK = 0xFFFFFFFFu; /* 4-gram kernel, GramK::g5peek: the state's record has to be looked at */
 constexpr int DENSE_THREADS = 1024; /* one workgroup per CU, 16 waves */
 /* dense kernel geometry: C = 64 bytes per lane-stream per tile, S = 2 streams per lane
@@ -856,7 +850,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const char *bloom_env = getenv ("ACM_GPU_BLOOM"); /* 0: no Bloom filters (experiments) */
   if (gram && !gram_wide && n_depth4 >= 2048 && !(bloom_env && atoi (bloom_env) == 0)) {
     const uint32_t lds_cap = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
-    const uint32_t gq_bytes = (SPARSE_THREADS / WAVE) * ((gram_shorts ? QCAP : 0u) + GRAM_Q1 + GRAM_Q2 + (gram_wide ? HITS_STRIDE : (ACM_GRAM_TWO_LEVEL ? GRAM_Q1B : 0u))) * 8;
+    const uint32_t gq_bytes = (SPARSE_THREADS / WAVE) * ((gram_shorts ? QCAP : 0u) + GRAM_Q1 + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
     bloom_off = (g3_off + g3_bytes + 15) & ~15u;
     const uint64_t used = (uint64_t)bloom_off + gq_bytes + WALK_CTX_BYTES + 64;
     uint32_t n_term4 = 0, n_5 = 0;
@@ -1048,7 +1042,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   p->d_dstart = u32p (o_dstart);
   if (gram) {
     const uint32_t lds_total = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
-    const uint32_t gq = (SPARSE_THREADS / WAVE) * ((gram_shorts ? QCAP : 0u) + GRAM_Q1 + GRAM_Q2 + (gram_wide ? HITS_STRIDE : (ACM_GRAM_TWO_LEVEL ? GRAM_Q1B : 0u))) * 8;
+    const uint32_t gq = (SPARSE_THREADS / WAVE) * ((gram_shorts ? QCAP : 0u) + GRAM_Q1 + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
     const uint32_t bits_bytes = bloom5_bits ? bloom_off + bloom_bytes : g3_off + g3_bytes;
     if ((uint64_t)bits_bytes + gq + WALK_CTX_BYTES <= lds_total) {
       p->d_kw4 = u32p (o_kw4);

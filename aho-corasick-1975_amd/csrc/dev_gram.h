@@ -147,8 +147,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
    * that is more than 33), short-keyword queue (QCAP, SHORTS only), hit buffer (wide alphabets) */
   constexpr bool DIRECT = !WIDE; /* narrow alphabets: 16-byte records straight into the caller's buffer (dev_starts.h: WaveRec), no hits */
   constexpr uint32_t HB = DIRECT ? 0u : HITS_STRIDE;
-  constexpr uint32_t Q1B = (WIDE || !ACM_GRAM_TWO_LEVEL) ? 0u : GRAM_Q1B; /* narrow alphabets: the queue between the filters and the gathers */
-  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (GRAM_Q1 + GRAM_Q2 + (NQ - 2) * QCAP + HB + Q1B) * 8);
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.queue_off + WAVES * (GRAM_Q1 + GRAM_Q2 + (NQ - 2) * QCAP + HB) * 8);
   StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4); /* see scan_starts_kernel */
   EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
   WaveRec *Ws = reinterpret_cast<WaveRec *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K + WALK_CTX_E); /* one per wave */
@@ -174,7 +173,6 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   uint2 *q1 = reinterpret_cast<uint2 *> (smem + K.queue_off) + wib * GRAM_Q1;
   uint2 *q2 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * GRAM_Q1 + wib * GRAM_Q2;
   uint2 *q3 = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * (GRAM_Q1 + GRAM_Q2) + wib * QCAP; /* SHORTS only */
-  uint2 *q1b = reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * (GRAM_Q1 + GRAM_Q2 + (NQ - 2) * QCAP + HB) + wib * Q1B;
   const uint32_t wave_id = blockIdx.x * WAVES + wib;
   uint2 *hits = DIRECT ? reinterpret_cast<uint2 *> (Ws + wib)
                        : reinterpret_cast<uint2 *> (smem + K.queue_off) + WAVES * (GRAM_Q1 + GRAM_Q2 + (NQ - 2) * QCAP) + wib * HITS_STRIDE + 2;
@@ -215,7 +213,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
    * handed to its waves through the LDS counter */
   const TileShare share (A);
   const uint32_t last_blk = (A.n - 1) / 16;
-  uint32_t qn1 = 0, qn2 = 0, qn3 = 0, qn1b = 0;
+  uint32_t qn1 = 0, qn2 = 0, qn3 = 0;
   unsigned long long counted = 0;
   RecState rs = { 0ull, 0u }; /* DIRECT: the wave's chunk of records (none yet, or the one a resumed scan left) */
   if (DIRECT && !COUNT_ONLY && resume) {
@@ -389,68 +387,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
    * the slot that frees up and send for their records.  Narrow alphabets: the new batch's two LDS
    * round trips (items; then the words of the two Bloom filters and of the 4-gram bits) are put
    * behind the two halves of the consumption -- four waves per SIMD do not hide them. */
-#if ACM_GRAM_TWO_LEVEL
-  /* Narrow alphabets, two levels.  Four of five first-queue items are in neither Bloom filter
-   * (19.6 % of the positions pass the 4-gram bits, 3.9 % the filters), yet in one level every
-   * batch of 64 paid for the whole second stage -- the pipeline's shifts, the terminal and pass
-   * tests of the oldest batch, the emit -- with 13 lanes of 64 at work: 0.47 of the kernel's
-   * 1.9 ms per 2 GiB (ablation builds, §4.3c).  Now a LIGHT step asks the filters and queues the
-   * survivors again (q1b), and the HEAVY step -- everything else -- runs on full batches of
-   * survivors, a fifth as often. */
-  auto heavy_step = [&] (uint32_t n_items) {
-    qn1b -= n_items;
-    const uint2 it = lane < n_items ? q1b[qn1b + lane] : make_uint2 (0, 0);
-    consume_terminal ();
-    const uint32_t idx = it.y & 0xFFFFFu;
-    const uint32_t word = *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> ((idx >> 5) * 4u);
-    consume_pass ();
-    pipeline_shift ();
-    pend_item[GRAM_DEPTH - 1] = it;
-    uint32_t pre = 0;
-    if (lane < n_items)
-      pre = K.g4prefix[idx >> 5];
-    pend_rx[GRAM_DEPTH - 1] = pre;
-    pend_ry[GRAM_DEPTH - 1] = __popc (word & ((1u << (idx & 31u)) - 1u)) | (lane < n_items ? PEND_NEED : 0u);
-    emit_stashed ();
-    pend_n[GRAM_DEPTH - 1] = n_items;
-  };
-  auto light_step = [&] (uint32_t n_items) {
-    qn1 -= n_items;
-    const uint2 it = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
-    const uint32_t idx = it.y & 0xFFFFFu, c5 = (it.y >> 20) & 31u;
-    const uint32_t scaleT = (K.bloomT_bits / 32) << 8, scale5 = (K.bloom5_bits / 32) << 8;
-    const uint32_t offT = K.bloom_off, off5 = K.bloom_off + K.bloomT_bits / 8;
-    auto lds_word = [&] (uint32_t byte_off) -> uint32_t {
-      return *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (byte_off);
-    };
-    /* one word per filter: both bits of a key lie in it (gram_bloom_slot); without filters scale 0
-     * reads some word and the answer is ignored */
-    const uint32_t h1 = __umul24 (idx, BLOOM_C1);
-    const uint32_t h3 = mad_u24 (c5, BLOOM_D1, h1);
-    const uint32_t w1 = lds_word (offT + mul_hi_u24 (h1, scaleT) * 4u);
-    const uint32_t w3 = lds_word (off5 + mul_hi_u24 (h3, scale5) * 4u);
-    const uint32_t tf = ((w1 >> (h1 & 31u)) & (w1 >> ((h1 >> 5) & 31u))) | ((w3 >> (h3 & 31u)) & (w3 >> ((h3 >> 5) & 31u))) | (K.bloom5_bits ? 0u : 1u);
-    const bool need = lane < n_items && (tf & 1u) != 0;
-    const uint64_t m = __ballot (need);
-    const uint32_t ns = (uint32_t)__popcll (m);
-    if (ns) {
-      if (__builtin_expect (qn1b + ns > GRAM_Q1B, 0)) /* (63 waiting + 64 survivors do not fit: rare -- a batch that is not full) */
-        heavy_step (qn1b < WAVE ? qn1b : WAVE);
-      if (need)
-        q1b[qn1b + rank_below (m)] = it;
-      qn1b = uniform (qn1b + ns);
-      while (qn1b >= WAVE)
-        heavy_step (WAVE);
-    }
-  };
-#endif
   auto batch_step = [&] (uint32_t n_items) {
-#if ACM_GRAM_TWO_LEVEL
-    if constexpr (!WIDE) {
-      light_step (n_items);
-      return;
-    }
-#endif
     qn1 -= n_items;
     const uint2 it = lane < n_items ? q1[qn1 + lane] : make_uint2 (0, 0);
     if constexpr (WIDE) {
@@ -700,10 +637,6 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
   auto drain = [&] () {
       if (qn1)
         batch_step (qn1);
-#if ACM_GRAM_TWO_LEVEL
-      if (!WIDE && qn1b)
-        heavy_step (qn1b);
-#endif
 #pragma unroll
       for (int d = 0; d < GRAM_DEPTH; d++)
         consume_oldest ();
