@@ -17,7 +17,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$name -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-other-configs > /dev/null 2> $OUT/pmc_$name.err || echo "pmc $name failed"
 done
 python3 - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, re
 out = {"command": "bench.py $ARGS"}
 f = glob.glob("$OUT/trace/*/*kernel_stats.csv")[0]
 out["kernel_stats"] = [dict(name=r["Name"][:110], calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), pct=float(r["Percentage"])) for r in csv.DictReader(open(f))][:14]
@@ -26,7 +26,7 @@ for f in glob.glob("$OUT/pmc_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         k = next((x for x in ("scan_dense_kernel", "scan_gram_kernel", "scan_starts_kernel", "expand_items", "expand_hits", "close_holes", "tile_gather", "tile_size", "order_bucket", "order_finish") if x in n), None)
-        if k == "scan_gram_kernel" and n.split("(")[0].rstrip().endswith(", true>"):
+        if k == "scan_gram_kernel" and re.search(r"scan_gram_kernel<[^>]*, true>", n):
             k = "scan_gram_kernel_tiled"   # (the e2e leg's scan: acm_gpu_scan_ordered_device)
         # record-mode instantiations only (the count-only pass that sizes the record buffer is another kernel)
         count_only = ("scan_gram_kernel<true" in n or
