@@ -216,7 +216,7 @@ tile_gather_kernel (TileK K) {
   uint32_t *ctr = reinterpret_cast<uint32_t *> (tile_smem);                                          /* crowded path */
   uint32_t *s_clist = reinterpret_cast<uint32_t *> (tile_smem + TILE_CROWDED_POSITIONS * 4);         /* crowded path */
   __shared__ uint32_t s_plist[TILE_LIST];
-  __shared__ uint32_t s_cnt[TILE_NSUB], s_off[TILE_NSUB];
+  __shared__ uint32_t s_cnt[TILE_NSUB], s_off[TILE_NSUB], s_cur[TILE_NSUB];
   __shared__ uint32_t s_nown, s_flag, s_part[TILE_THREADS / WAVE];
   static_assert (TILE_SRC_MAX <= (TILE_LIST - 1) * REC_CHUNK, "a tile of the normal path lies within the chunks a TileRun lists");
   static_assert (TILE_NSUB <= WAVE && TILE_SUBCAP <= 256, "one lane per bucket; a record's place in its bucket is a byte");
@@ -332,21 +332,94 @@ tile_gather_kernel (TileK K) {
       return *reinterpret_cast<const uint4 *> (&K.raw[slot]);
     };
     auto kept = [&] (uint32_t i, unsigned long long pos) -> bool { return i < n_own ? pos < e.hi : pos >= e.lo; };
-    /* crowded tile: bucket by bucket a counting sort over the bucket's positions (order_count_role
-     * does the same for a bucket of the general path), the tile's source streamed twice per bucket */
+    /* Crowded tile (more than TILE_SRC_MAX source records, or a bucket of more than TILE_SUBCAP):
+     * the source is read twice -- the buckets' counts, then the records written to the tile's
+     * stretch of the output GROUPED by bucket -- and every bucket is then put in order where it
+     * lies: up to TILE_SRC_MAX records by a counting sort over its 2,048 positions with the
+     * records held in registers between the loads and the stores (order_count_role does the same
+     * out of place for a bucket of the general path); a bucket with more than that -- more than a
+     * record per position -- the same way but streaming the tile's source twice more.  (First
+     * form: every bucket streamed the whole tile twice; 2 GiB with 0.18 records per symbol took
+     * 42 ms where the three general passes take 18.) */
     constexpr uint32_t POSITIONS = TILE_CROWDED_POSITIONS, PER = POSITIONS / TILE_THREADS;
+    static_assert (POSITIONS == (1u << TILE_BUCKET_LOG2), "the crowded path sorts a bucket at a time");
+    auto bucket_of = [&] (unsigned long long pos) -> uint32_t {
+      uint32_t sub = (uint32_t)((pos - e.lo) >> TILE_BUCKET_LOG2);
+      if (pos < e.lo || sub >= K.nsub) { /* (never expected) */
+        if (K.error)
+          *K.error = 1;
+        sub = K.nsub - 1;
+      }
+      return sub;
+    };
+    __syncthreads ();
+    if (tid < TILE_NSUB)
+      s_cnt[tid] = 0;
+    __syncthreads ();
+    for (uint32_t i = tid; i < n_src; i += TILE_THREADS) {
+      const uint4 rec = source (i);
+      const unsigned long long pos = ((unsigned long long)rec.y << 32) | rec.x;
+      if (kept (i, pos))
+        atomicAdd (&s_cnt[bucket_of (pos)], 1u);
+    }
+    __syncthreads ();
+    {
+      const uint32_t mine = lane < K.nsub ? s_cnt[lane] : 0u;
+      const uint32_t incl = wave_incl_scan (mine);
+      if (wid == 0 && lane < K.nsub)
+        s_off[lane] = s_cur[lane] = incl - mine;
+      const uint32_t kept_all = __shfl (incl, WAVE - 1, WAVE);
+      if (tid == 0 && kept_all != size && K.error)
+        *K.error = 1;
+    }
+    __syncthreads ();
+    for (uint32_t i = tid; i < n_src; i += TILE_THREADS) {
+      const uint4 rec = source (i);
+      const unsigned long long pos = ((unsigned long long)rec.y << 32) | rec.x;
+      if (kept (i, pos)) {
+        const uint32_t slot = atomicAdd (&s_cur[bucket_of (pos)], 1u);
+        if (slot < size)
+          *reinterpret_cast<uint4 *> (&K.out[out_begin + slot]) = rec;
+      }
+    }
+    /* the block's own stores, then its loads of them (one CU: the L1 all its waves share) */
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+    __syncthreads ();
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
     uint32_t done = 0;
-    for (uint32_t sb = 0; sb < K.nsub * ((1u << TILE_BUCKET_LOG2) / POSITIONS) && done < size; sb++) {
+    for (uint32_t sb = 0; sb < K.nsub; sb++) {
+      const uint32_t in_bucket = s_cnt[sb];
+      if (in_bucket == 0)
+        continue;
+      ACMRecord *dst = K.out + out_begin + s_off[sb];
+      const bool held = in_bucket <= TILE_SRC_MAX; /* the bucket's records fit the block's registers */
+      const unsigned long long b_lo = e.lo + (unsigned long long)sb * POSITIONS, b_hi = b_lo + POSITIONS;
       __syncthreads ();
       for (uint32_t i = tid; i < POSITIONS; i += TILE_THREADS)
         ctr[i] = 0;
+      uint4 rec[TILE_PER];
+      if (held) {
+#pragma unroll
+        for (uint32_t q = 0; q < TILE_PER; q++) {
+          const uint32_t i = q * TILE_THREADS + tid;
+          rec[q] = make_uint4 (0, 0, 0, 0);
+          if (i < in_bucket)
+            rec[q] = *reinterpret_cast<const uint4 *> (&dst[i]);
+        }
+      }
       __syncthreads ();
-      const unsigned long long b_lo = e.lo + (unsigned long long)sb * POSITIONS, b_hi = b_lo + POSITIONS;
-      for (uint32_t i = tid; i < n_src; i += TILE_THREADS) {
-        const uint4 rec = source (i);
-        const unsigned long long pos = ((unsigned long long)rec.y << 32) | rec.x;
-        if (kept (i, pos) && pos >= b_lo && pos < b_hi)
-          atomicAdd (&ctr[(uint32_t)(pos - b_lo)], 1u);
+      if (held) {
+#pragma unroll
+        for (uint32_t q = 0; q < TILE_PER; q++)
+          if (q * TILE_THREADS + tid < in_bucket)
+            atomicAdd (&ctr[(uint32_t)((((unsigned long long)rec[q].y << 32) | rec[q].x) - b_lo) & (POSITIONS - 1)], 1u);
+      } else {
+        for (uint32_t i = tid; i < n_src; i += TILE_THREADS) {
+          const uint4 r = source (i);
+          const unsigned long long pos = ((unsigned long long)r.y << 32) | r.x;
+          if (kept (i, pos) && pos >= b_lo && pos < b_hi)
+            atomicAdd (&ctr[(uint32_t)(pos - b_lo)], 1u);
+        }
       }
       __syncthreads ();
       uint32_t run = 0;
@@ -357,31 +430,33 @@ tile_gather_kernel (TileK K) {
       if (lane == WAVE - 1)
         s_part[wid] = incl;
       __syncthreads ();
-      uint32_t acc = incl - run, in_bucket = 0;
-      for (uint32_t w = 0; w < TILE_THREADS / WAVE; w++) {
-        if (w < wid)
-          acc += s_part[w];
-        in_bucket += s_part[w];
-      }
+      uint32_t acc = incl - run;
+      for (uint32_t w = 0; w < wid; w++)
+        acc += s_part[w];
 #pragma unroll
       for (uint32_t q = 0; q < PER; q++) {
         const uint32_t c = ctr[tid * PER + q];
         ctr[tid * PER + q] = acc;
         acc += c;
       }
-      __syncthreads ();
-      if (in_bucket == 0)
-        continue;
-      ACMRecord *dst = K.out + out_begin + done;
-      for (uint32_t i = tid; i < n_src; i += TILE_THREADS) {
-        const uint4 rec = source (i);
-        const unsigned long long pos = ((unsigned long long)rec.y << 32) | rec.x;
-        if (kept (i, pos) && pos >= b_lo && pos < b_hi) {
-          const uint32_t slot = atomicAdd (&ctr[(uint32_t)(pos - b_lo)], 1u);
-          *reinterpret_cast<uint4 *> (&dst[slot]) = rec;
+      __syncthreads (); /* (every load of the bucket's records lies in front of this: the stores may begin) */
+      if (held) {
+#pragma unroll
+        for (uint32_t q = 0; q < TILE_PER; q++)
+          if (q * TILE_THREADS + tid < in_bucket) {
+            const uint32_t slot = atomicAdd (&ctr[(uint32_t)((((unsigned long long)rec[q].y << 32) | rec[q].x) - b_lo) & (POSITIONS - 1)], 1u);
+            *reinterpret_cast<uint4 *> (&dst[slot]) = rec[q];
+          }
+      } else {
+        for (uint32_t i = tid; i < n_src; i += TILE_THREADS) {
+          const uint4 r = source (i);
+          const unsigned long long pos = ((unsigned long long)r.y << 32) | r.x;
+          if (kept (i, pos) && pos >= b_lo && pos < b_hi) {
+            const uint32_t slot = atomicAdd (&ctr[(uint32_t)(pos - b_lo)], 1u);
+            *reinterpret_cast<uint4 *> (&dst[slot]) = r;
+          }
         }
       }
-      /* the block's own stores, then its loads of them (one CU: the L1 all its waves share) */
       __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
       __syncthreads ();
       __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");

@@ -378,6 +378,41 @@ def test_scan_ordered_one_call_equals_scan_then_order(torch_cuda, monkeypatch, k
     assert np.array_equal(plan.scan_sorted(_dev(torch, one)), o.scan(one))
 
 
+def test_tiled_order_every_position_full_of_matches(torch_cuda, monkeypatch):
+    """The tiled scan's ordering pass (dev_tiles.h) on the densest texts a 4-gram plan can see: nested
+    keywords a^4 .. a^12 in a text of a's -- nine records per position, a bucket of 2,048 positions
+    holds 18,000: the path that streams the tile; the same with stretches of other letters between
+    (buckets of a few hundred to two thousand records: sorted in registers where they lie); both
+    against the oracle, whole and from a cut, and against the three general passes."""
+    monkeypatch.setenv("ACM_GPU_GRAM", "2")
+    kws = [b"a" * k for k in range(4, 13)] + [b"abab", b"baba", b"aabb"]
+    m, o = build_pair(kws, 1)
+    plan = m.plan(0)
+    assert plan.info.kernel == 5 and plan.info.records_direct == 1
+    rng = np.random.default_rng(99)
+    solid = np.full(60000, ord("a"), dtype=np.uint8)
+    mixed = solid.copy()
+    for at in rng.integers(0, mixed.size - 40, size=900):       # islands of b's: the runs of a's get shorter
+        mixed[at:at + int(rng.integers(1, 40))] = ord("b")
+    for text in (solid, mixed):
+        want = o.scan(text)
+        dev = _dev(torch_cuda, text)
+        got = plan.scan_sorted(dev, capacity=want.size)
+        assert got.size == want.size and np.array_equal(got, want)
+        cut = 33333
+        assert np.array_equal(plan.scan_sorted(dev, emit_from=cut, pos_base=1 << 40, capacity=want.size),
+                              _shifted(want[want["end_pos"] >= cut], 1 << 40))
+        monkeypatch.setenv("ACM_GPU_ORDER", "buckets")
+        assert np.array_equal(plan.scan_sorted(dev, capacity=want.size), want)
+        monkeypatch.delenv("ACM_GPU_ORDER")
+
+
+def _shifted(rec, by):
+    r = rec.copy()
+    r["end_pos"] += by
+    return r
+
+
 def test_dense_matches_everywhere(torch_cuda):
     """Output blow-up: nested keywords matching at every position (queue flush path)."""
     kws = [b"a" * k for k in range(1, 9)] + [b"ab", b"b"]
