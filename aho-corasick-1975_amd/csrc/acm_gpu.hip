@@ -1557,6 +1557,9 @@ gram_tiling (const ACMPlan *p, uint32_t n, uint32_t emit_from) {
     R = 4;
   if (R > 64)
     R = 64;
+  static const int r_env = getenv ("ACM_GPU_GRAM_R") ? atoi (getenv ("ACM_GPU_GRAM_R")) : 0; /* experiments: groups per tile (a multiple of 4, up to 64) */
+  if (r_env >= 4 && r_env <= 64 && r_env % 4 == 0)
+    R = (uint64_t)r_env;
   GramTiling t;
   t.R = (uint32_t)R;
   t.begin = first_group / (uint32_t)R;
@@ -2701,7 +2704,7 @@ struct TiledPlan {
   uint32_t n_tiles = 0;
   uint64_t raw_slots = 0;
   uint32_t len_bits = 1, nsub = 2;
-  size_t o_raw = 0, o_prev = 0, o_dir = 0, o_size = 0, o_begin = 0, o_cub = 0, cub_bytes = 0, total = 0;
+  size_t o_raw = 0, o_prev = 0, o_dir = 0, o_size = 0, o_begin = 0, o_crowded = 0, o_cub = 0, cub_bytes = 0, total = 0;
 };
 
 /* the tiles of all the launches scan_impl makes for this text (the same walk over the segments) */
@@ -2743,6 +2746,7 @@ tiled_layout (const ACMPlan *p, uint64_t capacity, uint64_t n, uint64_t emit_fro
   L.o_dir = blob_reserve (cur, (size_t)L.n_tiles * sizeof (TileEntry));
   L.o_size = blob_reserve (cur, ((size_t)L.n_tiles + 1) * 4);
   L.o_begin = blob_reserve (cur, ((size_t)L.n_tiles + 1) * 4);
+  L.o_crowded = blob_reserve (cur, ((size_t)L.n_tiles + 1) * 4);
   L.o_cub = blob_reserve (cur, cub + 16);
   L.total = cur + 256;
   L.ok = true;
@@ -2779,6 +2783,7 @@ scan_tiled (ACMPlan *plan, const TiledPlan &L, const void *d_text, uint64_t n_sy
   K.reserved = plan->d_total;
   K.len_bits = L.len_bits;
   K.nsub = L.nsub;
+  K.crowded = reinterpret_cast<uint32_t *> (t + L.o_crowded);
   K.error = reinterpret_cast<unsigned int *> (plan->d_total) + 3;
   const uint32_t sblocks = (L.n_tiles + 1 + 3) / 4;
   hipLaunchKernelGGL (tile_size_kernel, dim3 (sblocks < (uint32_t)plan->cu_count * 16 ? sblocks : (uint32_t)plan->cu_count * 16), dim3 (256), 0, st, K);
@@ -2787,6 +2792,10 @@ scan_tiled (ACMPlan *plan, const TiledPlan &L, const void *d_text, uint64_t n_sy
   HIP_TRY (hipcub::DeviceScan::ExclusiveSum (t + L.o_cub, cub, K.size, reinterpret_cast<uint32_t *> (t + L.o_begin), (int)(L.n_tiles + 1), st));
   const uint32_t gblocks = L.n_tiles < (uint32_t)plan->cu_count * 16 ? L.n_tiles : (uint32_t)plan->cu_count * 16;
   hipLaunchKernelGGL (tile_gather_kernel, dim3 (gblocks), dim3 (TILE_THREADS), tile_lds_bytes (L.nsub), st, K);
+  HIP_TRY (hipGetLastError ());
+  /* the tiles it found crowded (dense matches; none on ordinary texts: the kernel returns at once) */
+  const uint32_t cblocks = L.n_tiles < (uint32_t)plan->cu_count * 4 ? L.n_tiles : (uint32_t)plan->cu_count * 4;
+  hipLaunchKernelGGL (tile_crowded_kernel, dim3 (cblocks), dim3 (TILE_THREADS), tile_lds_bytes (L.nsub), st, K);
   HIP_TRY (hipGetLastError ());
   return ACM_GPU_OK;
 }

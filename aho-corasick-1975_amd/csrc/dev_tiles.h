@@ -48,6 +48,7 @@ struct TileK {
   unsigned long long *reserved; /* the plan's running total (slots reserved by the scan): zeroed */
   uint32_t len_bits;
   uint32_t nsub;               /* buckets of 2,048 positions a tile spans at most (its groups / 2 + 1) */
+  uint32_t *crowded;           /* [1 + n_tiles] how many tiles tile_gather_kernel left to tile_crowded_kernel, then which */
   unsigned int *error;
 };
 
@@ -164,6 +165,8 @@ __global__ __launch_bounds__ (256) void
 tile_size_kernel (TileK K) {
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves = gridDim.x * blockDim.x / WAVE;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    K.crowded[0] = 0;
   for (uint32_t d = wave; d <= K.n_tiles; d += waves) {
     uint32_t sz = 0;
     if (d < K.n_tiles) {
@@ -214,11 +217,7 @@ tile_gather_kernel (TileK K) {
   extern __shared__ __attribute__ ((aligned (16))) unsigned char tile_smem[]; /* tile_lds_bytes (K.nsub) */
   uint32_t *s_key = reinterpret_cast<uint32_t *> (tile_smem);
   uint16_t *s_rank = reinterpret_cast<uint16_t *> (tile_smem + (size_t)K.nsub * TILE_SUBCAP * 4);
-  uint32_t *ctr = reinterpret_cast<uint32_t *> (tile_smem);                                          /* crowded path */
-  uint32_t *s_clist = reinterpret_cast<uint32_t *> (tile_smem + TILE_CROWDED_POSITIONS * 4);         /* crowded path */
-  __shared__ uint32_t s_plist[TILE_LIST];
-  __shared__ uint32_t s_cnt[TILE_NSUB], s_off[TILE_NSUB], s_cur[TILE_NSUB];
-  __shared__ uint32_t s_nown, s_flag, s_part[TILE_THREADS / WAVE];
+  __shared__ uint32_t s_cnt[TILE_NSUB], s_off[TILE_NSUB];
   static_assert (TILE_SRC_MAX <= (TILE_LIST - 1) * REC_CHUNK, "a tile of the normal path lies within the chunks a TileRun lists");
   static_assert (TILE_NSUB <= WAVE && TILE_SUBCAP <= 256, "one lane per bucket; a record's place in its bucket is a byte");
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
@@ -315,6 +314,35 @@ tile_gather_kernel (TileK K) {
         continue;
       }
     }
+    /* crowded: left to tile_crowded_kernel (a kernel of its own: its registers -- a bucket's records
+     * held between loads and stores -- would halve this one's occupancy) */
+    if (tid == 0)
+      K.crowded[1 + atomicAdd (&K.crowded[0], 1u)] = d;
+  }
+}
+
+/* Crowded tiles (more than TILE_SRC_MAX source records, or a bucket of more than TILE_SUBCAP), a
+ * block each. */
+__global__ __launch_bounds__ (TILE_THREADS) void
+tile_crowded_kernel (TileK K) {
+  extern __shared__ __attribute__ ((aligned (16))) unsigned char tile_smem[]; /* tile_lds_bytes (K.nsub) */
+  uint32_t *ctr = reinterpret_cast<uint32_t *> (tile_smem);
+  uint32_t *s_clist = reinterpret_cast<uint32_t *> (tile_smem + TILE_CROWDED_POSITIONS * 4);
+  __shared__ uint32_t s_plist[TILE_LIST];
+  __shared__ uint32_t s_cnt[TILE_NSUB], s_off[TILE_NSUB], s_cur[TILE_NSUB];
+  __shared__ uint32_t s_nown, s_flag, s_part[TILE_THREADS / WAVE];
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+  if ((unsigned long long)K.begin[K.n_tiles] > K.capacity)
+    return;
+  const uint32_t n_list = K.crowded[0];
+  for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+    const uint32_t d = K.crowded[1 + li];
+    const uint32_t out_begin = K.begin[d], size = K.begin[d + 1] - out_begin;
+    const TileEntry e = K.dir[d];
+    TileEntry ep = K.dir[d ? d - 1 : 0];
+    if (d == 0)
+      ep.n = ep.n_late = 0;
+    const uint32_t n_own = e.n, n_prev = ep.n_late < ep.n ? ep.n_late : ep.n, n_src = n_own + n_prev;
     /* crowded tile: the chunk lists in LDS (they may be long), then ... */
     __syncthreads ();
     if (tid == 0) {
