@@ -151,6 +151,12 @@ order_bucket_kernel (OrderK K, uint32_t *hist, ACMRecord *out) {
         break;
     }
     uint32_t at = 0;
+#if defined(ACM_ORDER_ABLATE) && ACM_ORDER_ABLATE == 1 /* experiment: pass A without its atomics */
+    if (!SCATTER) {
+      asm volatile ("" :: "v"(my_bucket), "v"(my_total), "v"(b[0]), "v"(b[7]));
+      continue;
+    }
+#endif
     if (lane < rounds) {
       if (SCATTER)
         at = atomicAdd (&hist[my_bucket], my_total); /* pass B: where this piece's run in the bucket begins */
