@@ -243,7 +243,12 @@ int acm_gpu_order_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t 
  * matches in this order; this is that loop's output, complete, with one synchronisation at the
  * end).  d_records[0 .. *d_count) is in canonical order afterwards when *d_count <= capacity; a
  * scan that overflowed leaves the total in *d_count and nothing in order (repeat it with room).
- * d_tmp must hold acm_gpu_scan_ordered_tmp_bytes(plan, capacity, n_symbols) bytes. */
+ * Plans of big byte dictionaries (the 4-gram kernel, narrow alphabets, keywords of up to 1,024
+ * symbols, no pending delta) scan in tiles into d_tmp and put the records in order in ONE pass
+ * over them; every other plan scans as acm_gpu_scan_device does and runs
+ * acm_gpu_order_records_device's passes behind it.  Same records, same order either way.
+ * d_tmp must hold acm_gpu_scan_ordered_tmp_bytes(plan, capacity, n_symbols) bytes (about
+ * 16 bytes per record of capacity, plus a few megabytes). */
 size_t acm_gpu_scan_ordered_tmp_bytes (const ACMPlan *plan, uint64_t capacity, uint64_t n_symbols);
 int acm_gpu_scan_ordered_device (ACMPlan *plan, const void *d_text, uint64_t n_symbols, uint64_t emit_from,
                                  uint64_t pos_base, ACMRecord *d_records, uint64_t capacity, uint64_t *d_count,
