@@ -2580,7 +2580,7 @@ order_layout (const ACMPlan *plan, uint64_t n, uint64_t span) {
   L.len_bits = len_bits;
   L.key_bits = span_bits + len_bits < 64 ? (int)(span_bits + len_bits) : 64;
   /* buckets of ORDER_POSITIONS positions (fewer when the whole range is shorter): whatever a
-   * bucket holds, order_count_kernel has a counter per position for it */
+   * bucket holds, order_count_role has a counter per position for it */
   uint32_t wlog = 0;
   while ((2u << wlog) <= ORDER_POSITIONS && (1ull << wlog) < span)
     wlog++;

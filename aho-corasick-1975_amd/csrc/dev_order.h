@@ -12,10 +12,12 @@
  *   B. exclusive prefix sum of the histogram (hipCUB), then the same walk again: every (piece,
  *      bucket) pair reserves its run in the bucket with one atomic and the records are copied
  *      there -- bucket by bucket the records are now in position order, unordered inside;
- *   C. every bucket is put in order and written to its final place: up to 64 records by one wave
+ *   C. every bucket is put in order and written to its final place: up to 256 records by one wave
  *      (rank = number of smaller keys), more by a counting sort over the bucket's positions in LDS
  *      (a bitonic sort of 4,096-record windows in LDS took 94 us per window: 19 ms on config 3).
- * Three passes over the records (one of them reads the positions only) instead of eight. */
+ * Three passes over the records (one of them reads the positions only) instead of eight.
+ * acm_gpu_scan_ordered_device queues them behind a scan with the record count read on the device
+ * (OrderK::n_dev); 4-gram plans take dev_tiles.h's single pass instead. */
 constexpr int ORDER_THREADS = 256, ORDER_PER = 8, ORDER_PIECE = ORDER_PER * WAVE; /* records a wave takes at a time */
 constexpr int ORDER_ROUNDS = 12; /* distinct buckets of a piece taken one at a time before the rest goes lane by lane */
 
@@ -190,12 +192,12 @@ order_bucket_kernel (OrderK K, uint32_t *hist, ACMRecord *out) {
 
 /* pass C.  A bucket covers 1 << wlog <= ORDER_POSITIONS positions; its records lie side by side in
  * `bucketed`, in no order.
- * order_small_kernel: buckets of at most 256 records, one wave each, four records per lane -- a
+ * order_small_role: buckets of at most 256 records, one wave each, four records per lane -- a
  * record's place is the number of records of the bucket with a smaller key (position, then longer
  * before shorter): one v_readlane and four compares per other record, no barrier, no LDS (a block
  * per bucket with a counting sort in LDS took 24 us per bucket of 200 records: five barriers with
  * a memory round trip between each).
- * order_count_kernel: the other buckets, one block each, whatever they hold (the records are
+ * order_count_role: the other buckets, one block each, whatever they hold (the records are
  * streamed, LDS holds a counter per position): a counting sort by position -- count, exclusive
  * prefix sums, place -- and then, position by position, the few records that end at the same
  * symbol put longest first. */
@@ -274,7 +276,7 @@ order_small_role (const OrderK &K, const uint32_t *__restrict__ P, const ACMReco
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint32_t wave = (blk * blockDim.x + threadIdx.x) / WAVE, waves = nblk * blockDim.x / WAVE;
   if (order_sparse (K, order_n (K)))
-    return; /* order_window_kernel's */
+    return; /* order_window_role's */
   for (uint32_t b = wave; b < K.n_buckets; b += waves) {
     const uint32_t base = uniform (P[b]), cnt = uniform (P[b + 1]) - base;
     if (cnt == 0 || cnt > ORDER_SMALL)
@@ -287,7 +289,7 @@ order_small_role (const OrderK &K, const uint32_t *__restrict__ P, const ACMReco
  * from the first bucket that begins at or after record 128 k to the first that begins at or after
  * record 128 (k + 1) -- ordered in one go when it holds at most 256 records; else (a crowded
  * bucket among sparse ones: the start of config 2's text has one of 934) its buckets one by one,
- * those of more than 256 left to order_count_kernel. */
+ * those of more than 256 left to order_count_role. */
 constexpr uint32_t ORDER_WINDOW = 128;
 /* the first bucket that begins at or after record `want` (P is ascending): the wave probes 64
  * places of the range at a time -- three dependent loads for config 2's 262,144 buckets where a
@@ -352,7 +354,7 @@ order_window_role (const OrderK &K, const uint32_t *__restrict__ P, const ACMRec
   const uint64_t wave = ((uint64_t)blk * blockDim.x + threadIdx.x) / WAVE, waves = (uint64_t)nblk * blockDim.x / WAVE;
   const uint64_t n = order_n (K);
   if (!order_sparse (K, n))
-    return; /* order_small_kernel's */
+    return; /* order_small_role's */
   const uint64_t windows = (n + ORDER_WINDOW - 1) / ORDER_WINDOW;
   for (uint64_t k = wave; k < windows; k += waves) {
     uint32_t b0, b1;
