@@ -13,6 +13,7 @@ RECORD_DTYPE = np.dtype([("end_pos", "<u8"), ("length", "<u4"), ("keyword_id", "
 ACM_GPU_OK = 0
 ACM_GPU_E_INELIGIBLE = -1
 ACM_GPU_E_OVERFLOW = -4
+ACM_GPU_E_ARG = -5
 
 
 class ACMError(RuntimeError):

@@ -370,6 +370,20 @@ def test_scan_ordered_one_call_equals_scan_then_order(torch_cuda, monkeypatch, k
         monkeypatch.setenv("ACM_GPU_ORDER", "radix")
         assert np.array_equal(plan.scan_sorted(dev, capacity=max(want.size, 1) + 100), want)
         monkeypatch.delenv("ACM_GPU_ORDER")
+    # scratch that is too small, a missing count: refused, nothing queued
+    L = acm.binding.lib()
+    dev = _dev(torch, texts[0])
+    rec = torch.empty((1000, 2), dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    need = L.acm_gpu_scan_ordered_tmp_bytes(plan.h, 1000, texts[0].size)
+    assert need > 16000
+    tmp = torch.empty(need, dtype=torch.uint8, device="cuda")
+    args = (plan.h, dev.data_ptr(), texts[0].size, 0, 0, rec.data_ptr(), 1000, cnt.data_ptr(), tmp.data_ptr())
+    assert L.acm_gpu_scan_ordered_device(*args, need - 1, None) == acm.binding.ACM_GPU_E_ARG
+    assert L.acm_gpu_scan_ordered_device(plan.h, dev.data_ptr(), texts[0].size, 0, 0, rec.data_ptr(), 1000, None, tmp.data_ptr(), need, None) == acm.binding.ACM_GPU_E_ARG
+    assert L.acm_gpu_scan_ordered_device(*args, need, None) == 0
+    torch.cuda.synchronize()
+    plan.status()
     # a text without any match, and one with exactly one
     blank = np.full(5000, 255 if sym == 1 else 65535, dtype=texts[0].dtype)
     assert plan.scan_sorted(_dev(torch, blank)).size == 0
