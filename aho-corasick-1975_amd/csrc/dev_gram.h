@@ -414,9 +414,17 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       const uint32_t h3 = mad_u24 (c5, BLOOM_D1, h1);
       const uint32_t w1 = lds_word (offT + mul_hi_u24 (h1, scaleT) * 4u);
       const uint32_t w3 = lds_word (off5 + mul_hi_u24 (h3, scale5) * 4u);
-      const uint32_t word = lds_word ((idx >> 5) * 4u);
+      /* the 4-gram bits' word: the plain kernel asks for it BEHIND the walks consume_pass may run
+       * (asked for beside the filters' words it was one register too many across them -- spilled,
+       * with a wait for all three LDS reads in front of the spill: 1.5 % of config 3); the tiled
+       * instantiation, whose registers fall differently, is 13 % slower that way and keeps it here */
+      uint32_t word = 0;
+      if constexpr (TILED)
+        word = lds_word ((idx >> 5) * 4u);
       consume_pass ();
       pipeline_shift ();
+      if constexpr (!TILED)
+        word = lds_word ((idx >> 5) * 4u);
       pend_item[GRAM_DEPTH - 1] = it;
       const uint32_t tf = ((w1 >> (h1 & 31u)) & (w1 >> ((h1 >> 5) & 31u))) | ((w3 >> (h3 & 31u)) & (w3 >> ((h3 >> 5) & 31u))) | (K.bloom5_bits ? 0u : 1u);
       /* (a lane that needs nothing asks for nothing: a gather costs by the line) */
