@@ -228,7 +228,13 @@ queue_drain (const EmitCtx &E, const uint2 *queue, uint32_t qn, Spill *sp, uint3
   /* PARK_ONLY (dense kernel): the caller has made room in the region (region_make_room), so there
    * is no call to flush_queue on this path -- it runs at every slow step of 128 unrolled ones */
   if (PARK_ONLY || (sp && sp->fill + qn <= sp->capacity)) {
-    for (uint32_t i = lane; i < qn; i += WAVE)
+    /* (the lane index through an opaque move: &queue[lane] is the same at every one of the dense
+     * kernel's 128 inlined slow steps, so the compiler hoisted it to the kernel's top, found no
+     * register for it over the whole kernel and kept it in scratch -- the record-mode kernel's one
+     * spilled VGPR; one v_lshl_add at the step that needs it instead) */
+    uint32_t l = lane;
+    asm volatile ("" : "+v"(l));
+    for (uint32_t i = l; i < qn; i += WAVE)
       sp->region[sp->fill + i] = queue[i];
     sp->fill = uniform (sp->fill + qn);
   } else
