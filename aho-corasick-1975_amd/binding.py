@@ -60,7 +60,7 @@ class PlanInfo(C.Structure):
     _fields_ = [("device", C.c_int)] + [(n, C.c_uint32) for n in (
         "kernel", "entry_bytes", "width", "dense_rows", "lds_rows", "lds_hotfail", "lds_bytes", "block_threads", "grid_blocks",
         "chunk_bytes", "streams")] + [("table_bytes", C.c_uint64), ("delta_keywords", C.c_uint32), ("merges", C.c_uint32),
-                                     ("records_direct", C.c_uint32), ("reserved", C.c_uint32)]
+                                     ("records_direct", C.c_uint32), ("variant", C.c_uint32)]
 
 
 _lib = None

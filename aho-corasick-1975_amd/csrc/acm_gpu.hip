@@ -50,133 +50,7 @@
     }                                                                                              \
   } while (0)
 
-#ifdef ACM_GRAM_NT_BOTH /* experiment builds (make expd D=...): non-temporal text loads and record stores in the 4-gram kernel */
-#define ACM_GRAM_NT_TEXT
-#define ACM_GRAM_NT_REC
-#endif
-
-/* Diagnostic build only (-DACM_DIAG, libac75_amd_diag.so, used by tools/diag_*.py): eight per-wave
- * counters (cycle stamps, call counts) whose meaning each kernel defines where it writes them.
- * Nothing of this exists in the product build. */
-#ifdef ACM_DIAG
-__device__ unsigned long long g_acm_diag[8192][8];
-#define DIAG(...) __VA_ARGS__
-#else
-#define DIAG(...)
-#endif
-
-namespace {
-
-constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr int WAVE = 64;
-constexpr int QCAP = 128;           /* per-wave queue of (position, state) items, 8 B each */
-constexpr uint32_t GRAM_Q2 = 96;    /* 4-gram kernel: per-wave queue of walk candidates */
-/* 4-gram kernel: its first queue (63 items waiting + up to 64 from one position).  Two other forms
- * of the push -- the fill in a vector register with the exec mask narrowed around the LDS write
- * (9.6 % slower), four positions' compares ahead of their scalar counts (19 % slower: 217 scalar
- * and 115 vector registers spilled) -- are tools/experiments/r03_gram_push_variants.patch */
-constexpr uint32_t GRAM_Q1 = 128;
-constexpr uint32_t GRAM_NO_PEEK = 0xFFFFFFFFu; /* 4-gram kernel, GramK::g5peek: the state's record has to be looked at */
-constexpr int DENSE_THREADS = 1024; /* one workgroup per CU, 16 waves */
-/* dense kernel geometry: C = 64 bytes per lane-stream per tile, S = 2 streams per lane
- * (-DACM_DENSE_S=n builds another stream count for experiments: 3 and 4 spill and are 2x slower) */
-#ifndef ACM_DENSE_S
-#define ACM_DENSE_S 2
-#endif
-/* a region must hold the items of two 16-step blocks beside a queue's worth: region_make_room */
-constexpr uint32_t DENSE_MIN_REGION_ITEMS = 2 * (16 * ACM_DENSE_S * WAVE + QCAP);
-constexpr uint64_t SEGMENT = 1ull << 31; /* symbols per launch: positions inside a launch are 32-bit */
-/* tests shrink it with ACM_GPU_SEGMENT_LOG2 to cross segment seams on small inputs */
-
-/* tables of the CSR kernel, states in breadth-first numbering (ACMFlatView) */
-struct CsrTables {
-  const uint32_t *row_ptr, *edge_sym, *edge_next, *fail, *nb_outputs;
-  uint32_t lmax;
-};
-
-/* what turns a queued (position, state) into records; states in breadth-first numbering.
- * oinfo[s] = { nb_outputs(s), next, length, keyword_id } describes the FIRST output of s (the
- * longest keyword ending there: s itself if terminal, else the nearest terminal state down its
- * failure chain) and `next` = the terminal state holding the following one: one 16-byte load per
- * record.  The second half serves the continuations of the dense kernel. */
-struct EmitCtx {
-  const uint4 *oinfo;
-  ACMRecord *records;
-  unsigned long long *count; /* running total of records: slots are reserved by atomicAdd on it */
-  uint64_t capacity, pos_base;
-  const unsigned char *text;  /* segment */
-  const uint32_t *wrows;      /* continuation rows of every state: next | out flag << 15 | depth(next) << 16 */
-  const uint16_t *cont_dh;    /* per state: depth of the nearest failure-chain state whose row is in LDS */
-  uint32_t W, lo, span, n, emit_from;
-  uint32_t chunk; /* bytes per lane-stream chunk of the dense kernel (a power of two) */
-  uint32_t n_states;
-  unsigned int *error; /* set to 1 if an item with an impossible state id is ever met (never expected) */
-  /* 4-gram kernels: keyword id of every depth-4 state by its rank among them (NONE: not a keyword).
-   * A hit whose state word carries HIT_LEN4 names such a state by that rank: its record is
-   * (position, 4, kw4[rank]) -- a 360 KB table that stays in L2 instead of the 16-byte output
-   * records of all 508,339 states (config 3: 26 of 27 M hits per GiB are keywords of 4 symbols) */
-  const uint32_t *kw4;
-  /* dense kernel, continuation mode: per rowless state s (index s - chain_base) what lies below
-   * it when that is ONE path to a leaf: { r | depth (hotfail (s)) << 4, leaf state t, the r <= 8
-   * symbols of the path }; r = 0: no such record (walk_continuation goes step by step), r = 15:
-   * s is a leaf.  NULL: none. */
-  const uint4 *chain;
-  uint32_t chain_base;
-  /* 4-gram kernel, narrow alphabets: records are written by the scan kernel itself into chunks of
-   * the caller's buffer (dev_starts.h: WaveRec); slots past `capacity` go to the plan's spill
-   * area, from which close_holes_kernel brings them back into the holes below the dense count */
-  uint4 *spill;
-  uint64_t spill_slots;
-  /* tiled scans (dev_tiles.h): `records` is a raw area of whole chunks, and a wave that reserves
-   * chunk c writes chunk_prev[c] = the chunk it filled before (NONE: its first) */
-  uint32_t *chunk_prev;
-};
-constexpr uint32_t HIT_LEN4 = 0x80000000u;
-/* the hit's word is the keyword itself: id (below 2^28) | length << 28 (1-3; 0: 4 symbols) | HIT_KW -- what
- * the 4-gram kernel's tables hold for the keywords of up to 4 symbols, so that their records need
- * no lookup (one in 13 positions of a text can end such a keyword) */
-constexpr uint32_t HIT_KW = 0x40000000u, HIT_KW_ID = 0x0FFFFFFFu;
-
-/* one launch: a segment of the buffer, positions relative to its first symbol */
-struct Launch {
-  const unsigned char *text; /* first symbol of the segment */
-  uint32_t n;                /* symbols in the segment */
-  uint32_t emit_from;        /* matches ending before this index are not reported */
-  uint32_t range_begin, range_end; /* dense: tile indices; csr: symbol indices */
-  /* dense: tiles [range_begin, static_end) are split evenly between the blocks; [static_end,
-   * range_end) is a pool in POOL_CLASSES equal parts, handed out tile by tile through pool_ctr */
-  uint32_t static_end, pool_class_tiles;
-  uint32_t pool_classes; /* min (POOL_CLASSES, blocks): block b draws from part b * pool_classes / blocks */
-  unsigned int *pool_ctr, *pool_reset; /* this launch's counters; the previous launch's, to zero */
-};
-static constexpr uint32_t POOL_CLASSES = 16, POOL_CTR_STRIDE = 64; /* counters 256 B apart */
-
-/* small uniform constants of the dense kernel */
-struct DenseK {
-  uint32_t W, rowbytes, lo, span;
-  uint32_t HD; /* states [0, HD): failure-resolved row in LDS */
-  uint32_t aux_off, queue_off, wub, lmax;
-  uint32_t stream_stride; /* 64 * C: distance between the chunks of a lane's consecutive streams */
-};
-
-/* queue item, second word, when the dense kernel runs in continuation mode (16-bit states) */
-constexpr uint32_t IT_STATE = 0x7FFFu;
-constexpr uint32_t IT_CONT = 1u << 15;  /* walk on from this (rowless) state: see walk_continuation */
-constexpr uint32_t IT_K_SHIFT = 16;     /* 12 bits: run-over step k (symbols past the end of the lane's chunk) */
-constexpr uint32_t IT_RUN = 1u << 28;   /* queued during a chunk's run-over */
-constexpr uint32_t IT_OUT = 1u << 29;   /* report the outputs of the state itself at pos */
-
-#include "dev_emit.h"
-#include "dev_dense.h"
-#include "dev_csr.h"
-#include "dev_sparse.h"
-#include "dev_starts.h"
-#include "dev_gram.h"
-#include "dev_misc.h"
-#include "dev_order.h"
-#include "dev_tiles.h"
-
-} // namespace
+#include "dev_all.h"
 
 /* ====================================================================== host side */
 /* Host mirror of the start-parallel tables of a plan that takes incremental updates
@@ -233,6 +107,7 @@ struct ACMPlan {
   GramK GK{};
   bool gram = false; /* 4-gram sieve kernel instead of the sticky dense walk */
   bool gram_shorts = false, gram_wide = false;
+  bool gram2 = false; /* scan_gram2_kernel (dev_gram2.h) instead of scan_gram_kernel */
   uint32_t gram_lds_bytes = 0;
   uint32_t class_sym_bytes = 0; /* comparator-class plans: the symbol size they were made for */
   bool sparse = false, sparse_lut_lds = false, starts_lut_lds = false;
@@ -396,7 +271,12 @@ starts_fn (bool lut_lds, bool count_only) {
 }
 
 const void *
-gram_kernel_ptr (bool count_only, bool shorts, bool wide, bool tiled = false) {
+gram_kernel_ptr (bool count_only, bool shorts, bool wide, bool tiled = false, bool gram2 = false) {
+  if (gram2) {
+    if (tiled)
+      return reinterpret_cast<const void *> (&scan_gram2_kernel<false, true>);
+    return count_only ? reinterpret_cast<const void *> (&scan_gram2_kernel<true, false>) : reinterpret_cast<const void *> (&scan_gram2_kernel<false, false>);
+  }
   if (tiled) /* (narrow alphabets, record mode) */
     return shorts ? reinterpret_cast<const void *> (&scan_gram_kernel<false, true, false, true>)
                   : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, false, true>);
@@ -519,6 +399,7 @@ struct GramImage {
   bool kw_inline;                          /* keyword ids fit a hit's word (HIT_KW) */
   bool peek_packed;                        /* 4 bytes per depth-5 state (fewer than 2^23 records) instead of 8 */
   uint32_t *g3, *stab;                     /* short keywords: prefix states per 3-gram (narrow) / table of tagged windows (wide) */
+  uint32_t *tab2, *prefix2;                /* scan_gram2_kernel: two bits per 4-gram (GramK::tab2), set even bits in front of each word; NULL: not made */
 };
 
 void
@@ -599,6 +480,15 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
       mask |= 1u << (fv.edge_sym[e] - fi.alpha_lo);
     bits[idx >> 5] |= 1u << (idx & 31);
+    if (G.tab2) {
+      /* T of this 4-gram; H of it when it is a keyword; H of the tails of the 5-grams below it */
+      G.tab2[idx >> 4] |= (fv.term_kw[st] != NONE ? 3u : 1u) << (2 * (idx & 15));
+      const uint32_t W3 = G.W * G.W * G.W;
+      for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++) {
+        const uint32_t tail = (idx % W3) * G.W + (fv.edge_sym[e] - fi.alpha_lo);
+        G.tab2[tail >> 4] |= 2u << (2 * (tail & 15));
+      }
+    }
     g4[2 * (size_t)idx] = mask;
     g4[2 * (size_t)idx + 1] = st;
     G.entry[3 * (size_t)(st - fv.depth_start[4])] = mask;
@@ -623,6 +513,11 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     for (uint32_t w = 0; w < words; w++) {
       G.prefix[w] = acc;
       acc += (uint32_t)__builtin_popcount (bits[w]);
+    }
+    acc = 0;
+    for (uint32_t w = 0; G.tab2 && w < (G.W * G.W * G.W * G.W + 15) / 16; w++) {
+      G.prefix2[w] = acc;
+      acc += (uint32_t)__builtin_popcount (G.tab2[w] & 0x55555555u);
     }
   }
   if (G.shorts && G.wide) {
@@ -872,6 +767,14 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     }
   }
   const uint32_t bloom_bytes = bloom5_bits ? (bloomT_bits + bloom5_bits) / 8 : 0;
+  /* scan_gram2_kernel (dev_gram2.h: lane-local sieve on two bits per 4-gram, no queue push per
+   * position, no Bloom filters): narrow alphabets without keywords of 1-3 symbols whose table fits
+   * LDS beside the waves' areas -- up to 26 symbols + "other".  ACM_GPU_GRAM2=0: scan_gram_kernel. */
+  const uint32_t tab2_words = gram && !gram_wide ? (gW4 + 15) / 16 : 0;
+  const uint32_t g2_off = (tab2_words * 4 + 15) & ~15u;
+  const char *gram2_env = getenv ("ACM_GPU_GRAM2");
+  const bool gram2 = gram && !gram_wide && !gram_shorts && !(gram2_env && atoi (gram2_env) == 0) &&
+                     (uint64_t)g2_off + G2_LDS_FIXED <= ((uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160u * 1024 : 64u * 1024);
   const size_t o_g4bits = blob_reserve (cur, gram ? (size_t)(bloom5_bits ? bloom_off + bloom_bytes : g3_off + g3_bytes) + 16 : 0);
   const size_t o_g3rec = blob_reserve (cur, gram_shorts && !gram_wide ? (size_t)gW3 * 16 : 0);
   const size_t o_stab = blob_reserve (cur, gram_wide && gram_shorts ? ((size_t)8 << stab_log2) : 0);
@@ -886,6 +789,8 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   /* peek entries of 4 bytes while a record index fits 23 bits (ACM_GPU_PEEK8=1: 8 bytes anyway -- tests) */
   const bool peek_packed = n < (1u << 23) && !(getenv ("ACM_GPU_PEEK8") && atoi (getenv ("ACM_GPU_PEEK8")) == 1);
   const size_t o_g5peek = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth5 * (peek_packed ? 4 : 8) + 16 : 0);
+  const size_t o_tab2 = blob_reserve (cur, gram2 ? (size_t)g2_off + 16 : 0);
+  const size_t o_prefix2 = blob_reserve (cur, gram2 ? (size_t)tab2_words * 4 + 16 : 0);
   p->blob_bytes = cur;
 
   std::vector<unsigned char> host (cur, 0);
@@ -940,6 +845,8 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     G.kw_base = kw_base;
     G.kw_inline = (uint64_t)fi.n_keywords + kw_base <= HIT_KW_ID;
     G.peek_packed = peek_packed;
+    G.tab2 = gram2 ? reinterpret_cast<uint32_t *> (&host[o_tab2]) : nullptr;
+    G.prefix2 = gram2 ? reinterpret_cast<uint32_t *> (&host[o_prefix2]) : nullptr;
     fill_gram_tables (fv, fi, G);
   }
   if (dense) {
@@ -1081,6 +988,14 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
       p->GK.W4 = gW4;
       p->GK.queue_off = bits_bytes;
       p->gram_lds_bytes = bits_bytes + gq + WALK_CTX_BYTES;
+      if (gram2) {
+        p->gram2 = true;
+        p->GK.tab2 = u32p (o_tab2);
+        p->GK.prefix2 = u32p (o_prefix2);
+        p->GK.tab2_words = tab2_words;
+        p->GK.g2_off = g2_off;
+        p->gram_lds_bytes = g2_off + G2_LDS_FIXED;
+      }
     }
   }
   if (sparse) {
@@ -1207,10 +1122,10 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   }
   if (p->gram) {
     for (int co = 0; co < 2; co++)
-      PLAN_TRY (hipFuncSetAttribute (gram_kernel_ptr (co != 0, p->gram_shorts, p->gram_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
+      PLAN_TRY (hipFuncSetAttribute (gram_kernel_ptr (co != 0, p->gram_shorts, p->gram_wide, false, p->gram2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)p->gram_lds_bytes));
     if (!p->gram_wide)
-      PLAN_TRY (hipFuncSetAttribute (gram_kernel_ptr (false, p->gram_shorts, false, true), hipFuncAttributeMaxDynamicSharedMemorySize,
+      PLAN_TRY (hipFuncSetAttribute (gram_kernel_ptr (false, p->gram_shorts, false, true, p->gram2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)p->gram_lds_bytes));
   }
   if (dense && !p->gram) {
@@ -1366,7 +1281,7 @@ acm_gpu_plan_info (const ACMPlan *plan, ACMPlanInfo *info) {
   info->delta_keywords = plan->delta ? plan->delta->finfo.n_keywords : 0;
   info->merges = plan->merges;
   info->records_direct = ((plan->gram && !plan->gram_wide) || plan->info.kernel == 2) ? 1u : 0u;
-  info->reserved = 0;
+  info->variant = plan->gram2 ? 2u : 0u;
 }
 
 extern "C" int
@@ -1545,6 +1460,7 @@ launch_starts (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_
 struct GramTiling {
   uint32_t R, begin, end;
 };
+constexpr uint32_t GRAM_R_MIN = 4; /* groups per tile, at least (tiled_layout's bound counts on it) */
 GramTiling
 gram_tiling (const ACMPlan *p, uint32_t n, uint32_t emit_from) {
   const uint32_t group = WAVE * 16;
@@ -1553,8 +1469,8 @@ gram_tiling (const ACMPlan *p, uint32_t n, uint32_t emit_from) {
   const uint32_t back = p->finfo.lmax > 1 ? p->finfo.lmax - 1 : 0;
   const uint32_t first_group = (emit_from > back ? emit_from - back : 0) / group;
   uint64_t R = (ngroups - first_group) / ((uint64_t)p->cu_count * wpb * 16);
-  if (R < 4)
-    R = 4;
+  if (R < GRAM_R_MIN)
+    R = GRAM_R_MIN;
   if (R > 64)
     R = 64;
   static const int r_env = getenv ("ACM_GPU_GRAM_R") ? atoi (getenv ("ACM_GPU_GRAM_R")) : 0; /* experiments: groups per tile (a multiple of 4, up to 64) */
@@ -1600,7 +1516,7 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t 
   if (dir)
     p->tiled_base += tiles;
   void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &items, &p->region_items, &fill, &holes, &resume, &dir, &dir_base };
-  HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts, p->gram_wide, dir != nullptr), dim3 (grid), dim3 (SPARSE_THREADS), args,
+  HIP_TRY (hipLaunchKernel (gram_kernel_ptr (COUNT_ONLY, p->gram_shorts, p->gram_wide, dir != nullptr, p->gram2), dim3 (grid), dim3 (SPARSE_THREADS), args,
                             p->gram_lds_bytes, st));
   if (stop)
     HIP_TRY (hipEventRecord (stop, st));
@@ -2704,12 +2620,17 @@ struct TiledPlan {
   uint32_t n_tiles = 0;
   uint64_t raw_slots = 0;
   uint32_t len_bits = 1, nsub = 2;
-  size_t o_raw = 0, o_prev = 0, o_dir = 0, o_size = 0, o_begin = 0, o_crowded = 0, o_cub = 0, cub_bytes = 0, total = 0;
+  size_t o_raw = 0, o_prev = 0, o_dir = 0, o_size = 0, o_begin = 0, o_crowded = 0, o_over = 0, o_cub = 0, cub_bytes = 0, total = 0;
 };
 
-/* the tiles of all the launches scan_impl makes for this text (the same walk over the segments) */
+/* the tiles of all the launches scan_impl makes for this text (the same walk over the segments).
+ * bound: an upper bound of the layout over every emit_from (acm_gpu_scan_ordered_tmp_bytes): the
+ * tiles are counted at the smallest R gram_tiling ever picks.  (Round 3 sized the scratch with
+ * emit_from = 0 "for the most tiles" -- but R = clamp (groups behind emit_from / (16 per wave), 4,
+ * 64), so a later emit_from can LOWER R and give more tiles than emit_from = 0: 1 GiB on 256 CUs
+ * is 16,384 tiles at emit_from = 0 and 20,480 when 81,919 groups are left.) */
 TiledPlan
-tiled_layout (const ACMPlan *p, uint64_t capacity, uint64_t n, uint64_t emit_from) {
+tiled_layout (const ACMPlan *p, uint64_t capacity, uint64_t n, uint64_t emit_from, bool bound = false) {
   TiledPlan L;
   const char *env = getenv ("ACM_GPU_ORDER"); /* radix / buckets: not this way (experiments, tests) */
   if (env && (strcmp (env, "radix") == 0 || strcmp (env, "buckets") == 0))
@@ -2725,7 +2646,12 @@ tiled_layout (const ACMPlan *p, uint64_t capacity, uint64_t n, uint64_t emit_fro
     const uint64_t seg_end = seg + SEG < n ? seg + SEG : n;
     const uint64_t read_begin = seg > halo ? seg - halo : 0;
     const uint64_t ef = emit_from > seg ? emit_from : seg;
-    const GramTiling T = gram_tiling (p, (uint32_t)(seg_end - read_begin), (uint32_t)(ef - read_begin));
+    GramTiling T = gram_tiling (p, (uint32_t)(seg_end - read_begin), (uint32_t)(ef - read_begin));
+    if (bound) { /* every group of the segment, GRAM_R_MIN groups per tile */
+      const uint32_t ngroups = (uint32_t)((seg_end - read_begin + WAVE * 16 - 1) / (WAVE * 16));
+      T.begin = 0;
+      T.end = (ngroups + GRAM_R_MIN - 1) / GRAM_R_MIN;
+    }
     tiles += T.end - T.begin;
     if (T.R * (WAVE * 16) / (1u << TILE_BUCKET_LOG2) + 1 > L.nsub)
       L.nsub = T.R * (WAVE * 16) / (1u << TILE_BUCKET_LOG2) + 1;
@@ -2747,6 +2673,7 @@ tiled_layout (const ACMPlan *p, uint64_t capacity, uint64_t n, uint64_t emit_fro
   L.o_size = blob_reserve (cur, ((size_t)L.n_tiles + 1) * 4);
   L.o_begin = blob_reserve (cur, ((size_t)L.n_tiles + 1) * 4);
   L.o_crowded = blob_reserve (cur, ((size_t)L.n_tiles + 1) * 4);
+  L.o_over = blob_reserve (cur, 8);
   L.o_cub = blob_reserve (cur, cub + 16);
   L.total = cur + 256;
   L.ok = true;
@@ -2784,6 +2711,9 @@ scan_tiled (ACMPlan *plan, const TiledPlan &L, const void *d_text, uint64_t n_sy
   K.len_bits = L.len_bits;
   K.nsub = L.nsub;
   K.crowded = reinterpret_cast<uint32_t *> (t + L.o_crowded);
+  K.raw_slots = L.raw_slots;
+  K.over_total = reinterpret_cast<unsigned long long *> (t + L.o_over);
+  HIP_TRY (hipMemsetAsync (K.over_total, 0, 8, st));
   K.error = reinterpret_cast<unsigned int *> (plan->d_total) + 3;
   const uint32_t sblocks = (L.n_tiles + 1 + 3) / 4;
   hipLaunchKernelGGL (tile_size_kernel, dim3 (sblocks < (uint32_t)plan->cu_count * 16 ? sblocks : (uint32_t)plan->cu_count * 16), dim3 (256), 0, st, K);
@@ -2812,7 +2742,7 @@ acm_gpu_scan_ordered_tmp_bytes (const ACMPlan *plan, uint64_t capacity, uint64_t
   if (!plan)
     return 0;
   const size_t general = acm_gpu_order_tmp_bytes (plan, capacity, n_symbols);
-  const TiledPlan L = tiled_layout (plan, capacity, n_symbols, 0); /* (emit_from = 0: the most tiles) */
+  const TiledPlan L = tiled_layout (plan, capacity, n_symbols, 0, true); /* (an upper bound over every emit_from) */
   return L.ok && L.total > general ? L.total : general;
 }
 
@@ -2824,7 +2754,9 @@ acm_gpu_scan_ordered_device (ACMPlan *plan, const void *d_text, uint64_t n_symbo
   if (capacity && tmp_bytes < acm_gpu_scan_ordered_tmp_bytes (plan, capacity, n_symbols))
     return ACM_GPU_E_ARG;
   const TiledPlan T = tiled_layout (plan, capacity, n_symbols, emit_from);
-  if (T.ok)
+  /* (the layout of THIS emit_from must fit what the caller gave -- the query is an upper bound, so
+   * it does; a buffer sized some other way takes the general passes, never a write past its end) */
+  if (T.ok && T.total <= tmp_bytes)
     return scan_tiled (plan, T, d_text, n_symbols, emit_from, pos_base, d_records, capacity, d_count, d_tmp, static_cast<hipStream_t> (stream));
   const OrderPlan L = order_layout (plan, capacity, n_symbols);
   int rc = acm_gpu_scan_device (plan, d_text, n_symbols, emit_from, pos_base, d_records, capacity, d_count, stream);

@@ -76,6 +76,13 @@ struct GramK {
   uint32_t d5_rel;        /* fewer than 2^24 depth-5 states: walk items name them by index and carry the 6th symbol's class */
   uint32_t R;             /* groups per tile */
   uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
+  /* scan_gram2_kernel (dev_gram2.h): two bits per 4-gram, staged in LDS -- bit 2i: "a keyword starts
+   * with 4-gram i" (the same as g4bits), bit 2i + 1: "4-gram i is a keyword, or the tail (symbols
+   * 2-5) of some keyword's first five"; prefix2[w] = set even bits in front of word w (the rank of
+   * a depth-4 state); g2_off: LDS offset of the waves' areas behind the table.  tab2 == NULL: the
+   * plan does not use that kernel. */
+  const uint32_t *tab2, *prefix2;
+  uint32_t tab2_words, g2_off;
 };
 
 constexpr uint32_t WIDE_H1 = 0x9E3779B1u, WIDE_H2 = 0x85EBCA6Bu; /* multiplicative hashes: Bloom bits, table slots */

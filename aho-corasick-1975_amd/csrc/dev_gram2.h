@@ -1,0 +1,453 @@
+/* dev_gram2.h -- scan_gram2_kernel: the 4-gram kernel with a lane-local sieve (narrow alphabets whose
+ * 2-bit table fits LDS, no keywords of 1-3 symbols).
+ * Device code of libac75_amd.so; included by dev_all.h inside its anonymous namespace.
+ *
+ * What it replaces (reference: the caller's loop acm_match -> acm_get_match, aho_corasick.c:434-482):
+ * scan_gram_kernel (dev_gram.h) asks one LDS bit per position -- "a keyword starts with this
+ * 4-gram", 19.6 % of config 3's positions -- and pushes the survivors into a per-wave queue position
+ * by position: ballot -> scalar count -> branch -> LDS write, 21 instructions in one dependent
+ * chain per position and wave, 0.42 of the 1.85 ms a count-only launch of 2 GiB takes, and the
+ * batches that empty the queue (Bloom filters in front of the rank gathers) another 0.47.  Here:
+ *   1. two bits per 4-gram in LDS, T = "a keyword starts with it" and H = "it IS a keyword of 4
+ *      symbols, or it is the TAIL (symbols 2-5) of some keyword's first five".  A position can
+ *      only have something to report if T (p) and (H (p) or H (p + 1)) -- its 4-gram is a keyword,
+ *      or its 5-gram can be a prefix: 7.4 % of config 3's positions instead of 19.6 %, for the
+ *      same one LDS word per position (the word of position p + 1 is read for p + 1 anyway).  No
+ *      Bloom filters: what is left is few enough to go straight to the rank gathers;
+ *   2. a lane keeps the answers of its 16 positions as bits of ONE register (one v_bfe + one
+ *      v_lshl_or per position, no ballot, no scalar instruction, no branch); per group of 1,024
+ *      positions one wave-wide prefix sum (DPP) says where every lane's survivors go, and the lanes
+ *      write their POSITIONS (2 bytes each) side by side into a list in LDS;
+ *   3. the group's text is staged in LDS (one ds_write_b128 per lane), so the lane that takes
+ *      survivor number s off the list rebuilds its item -- 4-gram index, classes of the 5th and
+ *      6th symbol -- from six bytes at a run-time LDS address (not a run-time register index);
+ *      batches of 64 are assembled in registers across groups and go through the same pipeline
+ *      of two dependent gathers (rank, then entry), terminal reports and walks as in
+ *      scan_gram_kernel.
+ * LDS: 2 x W^4 bits (a-z + "other": 132,864 B) + per wave 1,040 B of staged text, 256 B of list and
+ * a walk queue of 64 items; alphabets of up to 26 symbols fit.  Everything else (tiles, records
+ * written by the wave itself into chunks of the caller's buffer, tiled scans with a directory,
+ * resumed segments) is scan_gram_kernel's. */
+constexpr uint32_t G2_STAGE = WAVE * 16 + 16; /* a group of text + the 8 bytes behind it (padded) */
+constexpr uint32_t G2_LIST = 128;             /* survivor positions listed per round, 2 bytes each */
+constexpr uint32_t G2_Q2 = 64;                /* walk queue, 8-byte items */
+constexpr uint32_t G2_WAVE_BYTES = G2_STAGE + G2_LIST * 2 + G2_Q2 * 8;
+static_assert (G2_WAVE_BYTES % 16 == 0, "the staged text is written 16 bytes per lane");
+constexpr uint32_t G2_LDS_FIXED = (SPARSE_THREADS / WAVE) * G2_WAVE_BYTES + WALK_CTX_BYTES; /* + the table */
+
+/* inclusive prefix sum over the wave in six DPP adds (row shifts, then the two row broadcasts);
+ * every lane must be active */
+__device__ __forceinline__ uint32_t
+wave_incl_scan_dpp (uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 -> rows 1, 3 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp (0, (int)v, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2, 3 */
+  return v;
+}
+
+template <bool COUNT_ONLY, bool TILED>
+__global__ __launch_bounds__ (SPARSE_THREADS) void
+scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
+                   uint32_t *fill, RecHole *holes, uint32_t resume, TileEntry *dir, uint32_t dir_base) {
+  (void)items;
+  (void)region_items;
+  (void)fill;
+  extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
+  constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
+  constexpr uint32_t GROUP = WAVE * 16;
+  {
+    uint4 *dst = reinterpret_cast<uint4 *> (smem);
+    const uint4 *src = reinterpret_cast<const uint4 *> (K.tab2);
+    for (uint32_t i = threadIdx.x; i < (K.tab2_words + 3) / 4; i += blockDim.x)
+      dst[i] = src[i];
+  }
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + K.g2_off + WAVES * G2_WAVE_BYTES);
+  StartsK *Ks = reinterpret_cast<StartsK *> (next_tile + 4); /* see scan_starts_kernel */
+  EmitCtx *Es = reinterpret_cast<EmitCtx *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K);
+  WaveRec *Ws = reinterpret_cast<WaveRec *> (reinterpret_cast<unsigned char *> (Ks) + WALK_CTX_K + WALK_CTX_E); /* one per wave */
+  if (threadIdx.x == 0) {
+    *next_tile = 0;
+    StartsK Kc{};
+    Kc.srec = K.srec;
+    Kc.sedge = K.sedge;
+    Kc.remap = K.g4gid;
+    Kc.remap_base = K.d5_begin;
+    Kc.peek = K.g5peek;
+    Kc.peek_packed = K.peek_packed;
+    Kc.peek_rel = K.d5_rel;
+    Kc.lo = K.lo;
+    Kc.span = K.span;
+    *Ks = Kc;
+    *Es = E;
+  }
+  __syncthreads ();
+
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint32_t wib = uniform (threadIdx.x / WAVE);
+  /* the wave's part of LDS, by byte offset (address space 3) */
+  const uint32_t stage_off = K.g2_off + wib * G2_WAVE_BYTES;
+  const uint32_t list_off = stage_off + G2_STAGE;
+  uint2 *q2 = reinterpret_cast<uint2 *> (smem + stage_off + G2_STAGE + G2_LIST * 2);
+  const uint32_t wave_id = blockIdx.x * WAVES + wib;
+  uint2 *hits = reinterpret_cast<uint2 *> (Ws + wib); /* records straight into the caller's buffer (dev_starts.h: WaveRec) */
+  if (lane == 0) {
+    /* (as in scan_gram_kernel: no chunk yet, or the chunk a resumed segment carries over) */
+    WaveRec w0{};
+    if (resume && !COUNT_ONLY && holes) {
+      const RecHole h = holes[wave_id];
+      if (h.len) {
+        const unsigned long long at = ((unsigned long long)h.start_hi << 32) | h.start_lo; /* first free slot */
+        const unsigned long long base = at + h.len - REC_CHUNK;
+        const bool below = base + REC_CHUNK <= E.capacity;
+        const bool above = base >= E.capacity && base - E.capacity + REC_CHUNK <= E.spill_slots;
+        const uint64_t dst = below ? reinterpret_cast<uint64_t> (&E.records[base]) : (above ? reinterpret_cast<uint64_t> (E.spill + (base - E.capacity)) : 0ull);
+        w0.dst_lo = (uint32_t)dst;
+        w0.dst_hi = (uint32_t)(dst >> 32);
+        w0.base_lo = (uint32_t)base;
+        w0.base_hi = (uint32_t)(base >> 32);
+        w0.limit = (below || above) ? REC_CHUNK : 0u;
+        w0.have = 1;
+        w0.pad[0] = REC_CHUNK - h.len; /* slots used */
+        w0.pad[1] = 1;
+        w0.prev1 = w0.prev2 = NONE;
+      }
+    }
+    if (!w0.have)
+      w0.prev1 = w0.prev2 = NONE;
+    Ws[wib] = w0;
+  }
+  const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
+  const TileShare share (A);
+  const uint32_t last_blk = (A.n - 1) / 16;
+  uint32_t qn2 = 0;
+  unsigned long long counted = 0;
+  RecState rs = { 0ull, 0u };
+  if (!COUNT_ONLY && resume) {
+    rs = rec_state_load (hits);
+    counted = uniform (reinterpret_cast<const WaveRec *> (hits)->pad[0]);
+  }
+  /* the batch that is being put together: lanes [0, pk) hold an item (position, 4-gram index |
+   * class of the 5th symbol << 20 | class of the 6th << 25) */
+  uint32_t it_x = 0, it_y = 0, pk = 0;
+  /* batches whose gathers are in flight: scan_gram_kernel's pipeline (slot 2: prefix count asked
+   * for + rank inside the word | NEED; slot 1: the entry; slot 0: looked at next) */
+  constexpr int GRAM_DEPTH = 3;
+  uint2 pend_item[GRAM_DEPTH];
+  uint32_t pend_rx[GRAM_DEPTH], pend_ry[GRAM_DEPTH], pend_rz[1] = { 0 }, pend_rw[1] = { 0 };
+  uint3 pend_e1 = make_uint3 (0, 0, 0);
+  uint32_t pend_n[GRAM_DEPTH];
+  constexpr uint32_t PEND_NEED = 0x80000000u;
+#pragma unroll
+  for (int d = 0; d < GRAM_DEPTH; d++) {
+    pend_item[d] = make_uint2 (0, 0);
+    pend_rx[d] = pend_ry[d] = 0;
+    pend_n[d] = 0;
+  }
+  auto lds_word = [&] (uint32_t byte_off) -> uint32_t {
+    return *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (byte_off);
+  };
+  auto load_group = [&] (uint32_t g) -> uint4 {
+    const uint32_t blk = g * WAVE + lane;
+    return text16[blk < last_blk ? blk : last_blk];
+  };
+  auto walk_batch = [&] (uint32_t n_items) {
+    const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, 2> (Ks, Es, text, q2, qn2, n_items, hits, counted);
+    qn2 = uniform ((uint32_t)(r >> 32));
+    counted = (uint32_t)r;
+    if (!COUNT_ONLY)
+      rs = rec_state_load (hits); /* (the walk may have gone on to the next chunk) */
+  };
+  bool st_term = false;
+  uint32_t st_pos = 0, st_what = 0;
+  auto consume_terminal = [&] () {
+    if (pend_n[0]) {
+      /* a keyword of 4 symbols ends here: reported at once, the entry brought its id along */
+      st_term = lane < pend_n[0] && (pend_rx[0] >> 31) && pend_item[0].x + 3 >= E.emit_from;
+      st_pos = pend_item[0].x + 3;
+      st_what = pend_rw[0];
+    } else
+      st_term = false;
+  };
+  auto emit_stashed = [&] () {
+    emit_terminals<COUNT_ONLY, true> (E, st_term, st_pos, st_what, 4u, lane, hits, counted, Es, &rs);
+    if (!COUNT_ONLY)
+      counted = uniform ((uint32_t)counted);
+    st_term = false;
+  };
+  auto consume_pass = [&] () {
+    if (pend_n[0]) {
+      const uint32_t c4 = (pend_item[0].y >> 20) & 31u;
+      const bool pass = lane < pend_n[0] && ((pend_rx[0] >> c4) & 1u);
+      const uint64_t m = __ballot (pass);
+      if (m) {
+        /* (a walk call handles one level of the newest items and never leaves more than it took,
+         * and every item ends within lmax levels) */
+        while (qn2 + (uint32_t)__popcll (m) > G2_Q2)
+          walk_batch (qn2 < WAVE ? qn2 : WAVE);
+        if (pass) { /* the depth-5 state, at the 5th symbol; the 6th symbol's class rides along (the walk's first look needs no text) */
+          const uint32_t st5 = pend_rz[0] + __popc (pend_rx[0] & ((1u << c4) - 1u));
+          q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 4, K.d5_rel ? (st5 - K.d5_begin) | ((pend_item[0].y >> 25) & 31u) << 24 : st5);
+        }
+        qn2 = uniform (qn2 + (uint32_t)__popcll (m));
+        while (qn2 >= WAVE)
+          walk_batch (WAVE);
+      }
+    }
+  };
+  auto pipeline_shift = [&] () {
+    pend_item[0] = pend_item[1];
+    pend_ry[0] = pend_ry[1];
+    pend_n[0] = pend_n[1];
+    pend_item[1] = pend_item[2];
+    pend_n[1] = pend_n[2];
+    pend_n[2] = 0;
+    /* the middle batch's entries came in one 12-byte gather (a register tuple: it stays where it
+     * landed until its words are copied out here, one step later) */
+    pend_rx[0] = pend_e1.x;
+    pend_rz[0] = pend_e1.y;
+    pend_rw[0] = pend_e1.z;
+    asm volatile ("" : "+v"(pend_rx[0]), "+v"(pend_ry[0]), "+v"(pend_rz[0]), "+v"(pend_rw[0]), "+v"(pend_item[0].x), "+v"(pend_item[0].y),
+                  "+v"(pend_item[1].x), "+v"(pend_item[1].y));
+    __builtin_amdgcn_sched_barrier (0);
+    const uint32_t rank = pend_rx[2] + (pend_ry[2] & ~PEND_NEED);
+    uint3 ent = make_uint3 (0, 0, 0);
+    if (pend_n[1] && (pend_ry[2] & PEND_NEED))
+      ent = *reinterpret_cast<const uint3 *> (K.g4entry + 3 * (size_t)rank);
+    pend_e1 = ent;
+    pend_ry[1] = K.d4_begin + rank;
+  };
+  auto consume_oldest = [&] () {
+    consume_terminal ();
+    emit_stashed ();
+    consume_pass ();
+    pipeline_shift ();
+  };
+  /* One pipeline step: the oldest batch is consumed, the n items in lanes [0, n) of (it_x, it_y)
+   * take the slot that frees up and send for their prefix counts. */
+  auto batch_step = [&] (uint32_t n_items) {
+    consume_terminal ();
+    const uint32_t idx = it_y & 0xFFFFFu;
+    const uint32_t word = lds_word ((idx >> 4) * 4u);
+    consume_pass ();
+    pipeline_shift ();
+    pend_item[GRAM_DEPTH - 1] = make_uint2 (it_x, it_y);
+    const uint32_t sh = (idx & 15u) * 2u;
+    /* (a lane that needs nothing asks for nothing: a gather costs by the line) */
+    const bool need = lane < n_items && ((word >> sh) & 1u) != 0;
+    uint32_t pre = 0;
+    if (need)
+      pre = K.prefix2[idx >> 4];
+    pend_rx[GRAM_DEPTH - 1] = pre;
+    pend_ry[GRAM_DEPTH - 1] = __popc (word & 0x55555555u & ((1u << sh) - 1u)) | (need ? PEND_NEED : 0u);
+    emit_stashed ();
+    pend_n[GRAM_DEPTH - 1] = n_items;
+  };
+
+  /* one group: cur = this lane's 16 bytes, (next_x, next_y) = the first 8 bytes of every lane of the next group */
+  auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t next_y, const uint32_t g, uint4 &prefetched) {
+    /* word 0 of the next lane (v_mov_b32_dpp wave_shl:1; lane 63 keeps `old`: word 0 of the next group's lane 0) */
+    uint32_t after = (uint32_t)__builtin_amdgcn_update_dpp ((int)uniform (next_x), (int)cur.x, 0x130, 0xf, 0xf, false);
+    /* (the group four ahead is asked for behind the first look at this one: scan_gram_kernel) */
+    asm volatile ("" : "+v"(after));
+    __builtin_amdgcn_sched_barrier (0);
+    prefetched = load_group (g + 4);
+    /* the group's text where the lanes that take its survivors off the list find it */
+    typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+    typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
+    *reinterpret_cast<__attribute__ ((address_space (3))) u32x4 *> (stage_off + lane * 16u) = u32x4{ cur.x, cur.y, cur.z, cur.w };
+    if (lane == 0)
+      *reinterpret_cast<__attribute__ ((address_space (3))) u32x2 *> (stage_off + GROUP) = u32x2{ next_x, next_y };
+    const uint32_t pos0 = g * GROUP + lane * 16;
+    const uint32_t w[5] = { cur.x, cur.y, cur.z, cur.w, after };
+#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 7 /* experiment: the text is streamed and staged, not looked at */
+    asm volatile ("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
+    return;
+#endif
+    uint32_t c[20];
+#pragma unroll
+    for (int j = 0; j < 20; j++) {
+      const uint32_t b = (w[j / 4] >> (8 * (j % 4))) & 0xFFu;
+      c[j] = min (b - K.lo, K.span);
+    }
+    /* symbols past the end of the segment count as outside the alphabet (only the last groups) */
+    if (pos0 + 20 > A.n) {
+#pragma unroll
+      for (int j = 0; j < 20; j++)
+        if (pos0 + j >= A.n)
+          c[j] = K.span;
+    }
+    uint32_t pair[19];
+#pragma unroll
+    for (int j = 0; j < 19; j++)
+      pair[j] = __umul24 (c[j], K.W) + c[j + 1];
+    const uint32_t W2 = K.W * K.W;
+    /* bits 2j, 2j + 1 of acc: T and H of this lane's position j */
+    uint32_t acc = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      uint32_t ix[8], word[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        ix[j] = __umul24 (pair[8 * h + j], W2) + pair[8 * h + j + 2];
+        word[j] = lds_word ((ix[j] >> 4) * 4u);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        acc |= __builtin_amdgcn_ubfe (word[j], ix[j] << 1, 2u) << (2 * (8 * h + j)); /* (v_bfe_u32 takes the low 5 bits of the offset itself; v_lshl_or_b32) */
+    }
+    /* H of the position behind the lane's last (the next lane's first) */
+    const uint32_t ix16 = __umul24 (pair[16], W2) + pair[18];
+    const uint32_t h16 = __builtin_amdgcn_ubfe (lds_word ((ix16 >> 4) * 4u), (ix16 << 1) | 1u, 1u);
+    /* T (j) and (H (j) or H (j + 1)), at the even bits */
+    uint32_t pass = acc & ((acc >> 1) | (acc >> 3) | (h16 << 30)) & 0x55555555u;
+#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 6 /* experiment: the sieve alone */
+    asm volatile ("" :: "v"(pass));
+    return;
+#endif
+    const uint32_t cnt = __popc (pass);
+    const uint32_t incl = wave_incl_scan_dpp (cnt);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane ((int)incl, WAVE - 1);
+    if (total == 0)
+      return;
+    uint32_t my = incl - cnt; /* number of this lane's next survivor among the group's */
+    const bool tail = g * GROUP + GROUP + 8 > A.n; /* (the last groups of the segment) */
+    for (uint32_t base = 0; base < total; base += G2_LIST) {
+      const uint32_t n_here = total - base < G2_LIST ? total - base : G2_LIST;
+      /* the positions (within the group) of the survivors base .. base + n_here - 1, side by side */
+      {
+        const uint32_t lim = base + n_here;
+        while (pass != 0 && my < lim) {
+          const uint32_t b = (uint32_t)__builtin_ctz (pass);
+          *reinterpret_cast<__attribute__ ((address_space (3))) uint16_t *> (list_off + (my - base) * 2u) = (uint16_t)(lane * 16u + (b >> 1));
+          pass &= pass - 1u;
+          my++;
+        }
+      }
+#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 5 /* experiment: the survivors are listed and dropped */
+      continue;
+#endif
+      for (uint32_t off = 0; off < n_here;) {
+        const uint32_t take = n_here - off < WAVE - pk ? n_here - off : WAVE - pk;
+        const bool mine = lane >= pk && lane < pk + take;
+        /* survivor off + (lane - pk): its position q in the group, the six symbols from there */
+        const uint32_t li = mine ? off + lane - pk : 0u;
+        const uint32_t q = *reinterpret_cast<const __attribute__ ((address_space (3))) uint16_t *> (list_off + li * 2u);
+        const uint32_t a = stage_off + (q & ~3u);
+        const uint32_t d0 = lds_word (a), d1 = lds_word (a + 4u), d2 = lds_word (a + 8u);
+        const uint32_t lo4 = __builtin_amdgcn_alignbyte (d1, d0, q), hi4 = __builtin_amdgcn_alignbyte (d2, d1, q);
+        uint32_t r[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const uint32_t b = ((k < 4 ? lo4 : hi4) >> (8 * (k % 4))) & 0xFFu;
+          r[k] = min (b - K.lo, K.span);
+        }
+        const uint32_t p = g * GROUP + q;
+        if (tail) {
+#pragma unroll
+          for (int k = 0; k < 6; k++)
+            if (p + k >= A.n)
+              r[k] = K.span;
+        }
+        const uint32_t idx = __umul24 (__umul24 (r[0], K.W) + r[1], W2) + __umul24 (r[2], K.W) + r[3];
+        const uint32_t y = idx | (r[4] << 20) | (r[5] << 25);
+        it_x = mine ? p : it_x;
+        it_y = mine ? y : it_y;
+        pk += take;
+        off += take;
+#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 4 /* experiment: the items are rebuilt and dropped */
+        if (pk == WAVE) {
+          asm volatile ("" :: "v"(it_x), "v"(it_y));
+          pk = 0;
+        }
+        continue;
+#endif
+        if (pk == WAVE) {
+          batch_step (WAVE);
+          pk = 0;
+        }
+      }
+    }
+  };
+
+  /* tiled scan: the wave's stream index = records it has written so far (up to a constant) */
+  static_assert (!TILED || !COUNT_ONLY, "tiled scans write their records themselves");
+  constexpr bool tiled = TILED;
+  auto stream_index = [&] (const WaveRec &w) -> uint32_t { return w.have ? (w.pad[1] - 1u) * REC_CHUNK + (uint32_t)counted : 0u; };
+  if (tiled && lane == 0)
+    Ws[wib].tile = NONE;
+  /* the batch in the making, the pipeline and the walk queue are emptied: when the text is
+   * through, and in a tiled scan behind every tile (all its records are then written, side by side) */
+  auto drain = [&] () {
+    if (pk) {
+      batch_step (pk);
+      pk = 0;
+    }
+#pragma unroll
+    for (int d = 0; d < GRAM_DEPTH; d++)
+      consume_oldest ();
+    while (qn2)
+      walk_batch (qn2 < WAVE ? qn2 : WAVE);
+  };
+  for (;;) {
+    const uint32_t tile = share.next (next_tile, lane);
+    if (tiled) {
+      drain ();
+      if (lane == 0) {
+        const WaveRec w = Ws[wib];
+        if (w.tile != NONE) {
+          const uint32_t s_end = stream_index (w), cur_tile = w.tile;
+          const uint32_t tile_begin = cur_tile * K.R * GROUP, tile_len = K.R * GROUP;
+          const uint32_t tile_end = A.n - tile_begin < tile_len ? A.n : tile_begin + tile_len;
+          TileEntry e;
+          e.end_slot = w.have ? (((unsigned long long)w.base_hi << 32) | w.base_lo) + (uint32_t)counted : 0ull;
+          e.lo = E.pos_base + (tile_begin > E.emit_from ? tile_begin : E.emit_from);
+          e.hi = E.pos_base + tile_end;
+          e.n = s_end - w.s_begin;
+          e.n_late = s_end - w.s_late;
+          e.c1 = w.prev1;
+          e.c2 = w.prev1 != NONE ? w.prev2 : NONE;
+          e.pad[0] = e.pad[1] = 0;
+          dir[dir_base + (cur_tile - A.range_begin)] = e;
+        }
+      }
+    }
+    if (tile == NONE)
+      break;
+    if (tiled && lane == 0) {
+      WaveRec *W = Ws + wib;
+      W->tile = tile;
+      W->s_begin = W->s_late = stream_index (*W);
+    }
+    const uint32_t g0 = tile * K.R;
+    uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
+    for (uint32_t k = 0; k < K.R; k++) {
+      uint4 n3;
+      if (tiled && k + 1 == K.R && lane == 0) /* (keywords are no longer than a group here: what ends beyond the tile starts in its last group) */
+        Ws[wib].s_late = stream_index (Ws[wib]);
+      walk_group (c0, c1.x, c1.y, g0 + k, n3);
+      c0 = c1;
+      c1 = c2;
+      c2 = c3;
+      c3 = n3;
+    }
+  }
+  if (!tiled)
+    drain ();
+  if (COUNT_ONLY) {
+    const uint32_t incl = wave_incl_scan ((uint32_t)counted);
+    const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
+    if (lane == 0 && total)
+      atomicAdd (E.count, (unsigned long long)total);
+  } else {
+    /* what is left of the wave's last chunk is a hole for close_holes_kernel */
+    if (lane == 0 && holes) {
+      const WaveRec w = Ws[wib];
+      const unsigned long long at = (((unsigned long long)w.base_hi << 32) | w.base_lo) + (uint32_t)counted;
+      RecHole h = { (uint32_t)at, (uint32_t)(at >> 32), w.have ? REC_CHUNK - (uint32_t)counted : 0u, 0u };
+      holes[wave_id] = h;
+    }
+  }
+}

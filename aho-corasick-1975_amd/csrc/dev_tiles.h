@@ -49,8 +49,21 @@ struct TileK {
   uint32_t len_bits;
   uint32_t nsub;               /* buckets of 2,048 positions a tile spans at most (its groups / 2 + 1) */
   uint32_t *crowded;           /* [1 + n_tiles] how many tiles tile_gather_kernel left to tile_crowded_kernel, then which */
+  /* A scan that reserved more slots than the raw area has (`*reserved` > raw_slots: far more
+   * records than the caller's capacity) dropped the chunks beyond it -- their records, and their
+   * chunk_prev links.  Nothing of the raw area is then looked at: tile_size_kernel adds the tiles'
+   * own counts up in 64 bits (*over_total, zero otherwise: the sizes and their prefix sums are 32
+   * bits wide) and the later kernels report that total and return. */
+  uint64_t raw_slots;
+  unsigned long long *over_total;
   unsigned int *error;
 };
+/* the scan's total when it is known not to fit (see TileK::over_total), else what the prefix sums say */
+__device__ __forceinline__ unsigned long long
+tile_total (const TileK &K) {
+  const unsigned long long over = *K.over_total;
+  return over ? over : (unsigned long long)K.begin[K.n_tiles];
+}
 
 /* the slot of the record j places in front of `end_slot` in its wave's stream (j = 0: the last one) */
 __device__ __forceinline__ unsigned long long
@@ -167,17 +180,25 @@ tile_size_kernel (TileK K) {
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, waves = gridDim.x * blockDim.x / WAVE;
   if (blockIdx.x == 0 && threadIdx.x == 0)
     K.crowded[0] = 0;
+  const bool over = __hip_atomic_load (K.reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > K.raw_slots;
+  unsigned long long sum = 0;
   for (uint32_t d = wave; d <= K.n_tiles; d += waves) {
     uint32_t sz = 0;
     if (d < K.n_tiles) {
       const TileEntry e = K.dir[d];
-      sz = e.n - tile_count_over (K, e, lane);
-      if (d)
-        sz += tile_count_over (K, K.dir[d - 1], lane);
+      if (over)
+        sum += e.n; /* (every record is one of its tile's own; the late ones only move between neighbours) */
+      else {
+        sz = e.n - tile_count_over (K, e, lane);
+        if (d)
+          sz += tile_count_over (K, K.dir[d - 1], lane);
+      }
     }
     if (lane == 0)
       K.size[d] = sz;
   }
+  if (over && lane == 0 && sum)
+    atomicAdd (K.over_total, sum);
 }
 
 /* a wave ranks the cnt <= TILE_SUBCAP keys key[0 .. cnt): rank[k] = number of smaller keys (they
@@ -221,7 +242,7 @@ tile_gather_kernel (TileK K) {
   static_assert (TILE_SRC_MAX <= (TILE_LIST - 1) * REC_CHUNK, "a tile of the normal path lies within the chunks a TileRun lists");
   static_assert (TILE_NSUB <= WAVE && TILE_SUBCAP <= 256, "one lane per bucket; a record's place in its bucket is a byte");
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-  const unsigned long long total = K.begin[K.n_tiles];
+  const unsigned long long total = tile_total (K);
   if (blockIdx.x == 0 && tid == 0) {
     *K.d_count = total;
     *K.reserved = 0;
@@ -344,7 +365,7 @@ tile_crowded_kernel (TileK K) {
   __shared__ uint32_t s_cnt[TILE_NSUB], s_off[TILE_NSUB], s_cur[TILE_NSUB];
   __shared__ uint32_t s_nown, s_flag, s_part[TILE_THREADS / WAVE];
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-  if ((unsigned long long)K.begin[K.n_tiles] > K.capacity)
+  if (tile_total (K) > K.capacity)
     return;
   const uint32_t n_list = K.crowded[0];
   for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {

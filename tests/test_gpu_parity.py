@@ -427,6 +427,71 @@ def _shifted(rec, by):
     return r
 
 
+def test_tiled_scratch_is_an_upper_bound_for_every_emit_from(torch_cuda, monkeypatch):
+    """acm_gpu_scan_ordered_tmp_bytes must cover the tiled layout of EVERY emit_from: the tile length
+    is picked from the groups behind emit_from, so a cut a little into the text can give MORE tiles
+    than emit_from = 0 (128 MiB on 256 CUs: R = 8 -> 16,384 tiles whole, R = 7 -> 18,725 from a cut of
+    ~1 KiB).  Exactly that many bytes of scratch with a canary behind them; the records from the cut
+    = the whole scan's from there on, and the canary is untouched."""
+    torch = torch_cuda
+    monkeypatch.setenv("ACM_GPU_GRAM", "2")
+    rng = np.random.default_rng(2024)
+    kws = [rng.integers(97, 123, size=rng.integers(4, 10)).astype(np.uint8) for _ in range(5000)]
+    m, _ = build_pair(kws, 1)
+    plan = m.plan(0)
+    assert plan.info.kernel == 5 and plan.info.records_direct == 1
+    n = 128 << 20
+    dev = torch.randint(97, 123, (n,), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+    whole_n = int(plan.count(dev).item())
+    cap = whole_n + 16
+    L = acm.binding.lib()
+    need = L.acm_gpu_scan_ordered_tmp_bytes(plan.h, cap, n)
+    canary = 1 << 20
+    tmp = torch.full((need + canary,), 0xA5, dtype=torch.uint8, device="cuda")
+    rec = torch.empty((cap, 2), dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rec0, cnt0, _ = plan.scan_ordered(dev, capacity=cap)
+    assert int(cnt0.item()) == whole_n
+    for cut in (1100, 5 * 1024 + 3, (n // 5) + 77, n - 4096):
+        rc = L.acm_gpu_scan_ordered_device(plan.h, dev.data_ptr(), n, cut, 0, rec.data_ptr(), cap, cnt.data_ptr(), tmp.data_ptr(), need, None)
+        assert rc == 0
+        k = int(cnt.item())
+        plan.status()
+        assert bool((tmp[need:] == 0xA5).all().item()), "scratch written past the size the query gave (cut %d)" % cut
+        first = int((rec0[:whole_n, 0] < cut).sum().item())
+        assert k == whole_n - first
+        assert bool(torch.equal(rec[:k], rec0[first:whole_n])), "cut %d" % cut
+
+
+def test_tiled_scan_far_more_records_than_the_raw_area_holds(torch_cuda, monkeypatch):
+    """A tiled scan into a buffer that is smaller than the record set by more than the raw area's
+    slack (one chunk per wave + 1: ~4.2 M slots on 256 CUs): the chunks beyond it are dropped with
+    their links, so the size pass must not follow them -- it reports the exact total (summed in 64
+    bits) and nothing else happens.  Then with room: the oracle's records."""
+    torch = torch_cuda
+    monkeypatch.setenv("ACM_GPU_GRAM", "2")
+    rng = np.random.default_rng(515)
+    kws = [rng.integers(97, 104, size=rng.integers(4, 13)).astype(np.uint8) for _ in range(12000)]
+    text = rng.integers(96, 105, size=(40 << 20) + 321).astype(np.uint8)
+    m, o = build_pair(kws, 1)
+    plan = m.plan(0)
+    assert plan.info.kernel == 5 and plan.info.records_direct == 1
+    want_n, want_d = o.scan_mt(text, 8)
+    slack = (plan.info.grid_blocks * 16 + 1) * 1024
+    assert want_n > 4096 + slack + 100000, (want_n, slack)
+    dev = _dev(torch, text)
+    for cap in (4096, 1 << 20):
+        rec, cnt, _ = plan.scan_ordered(dev, capacity=cap)
+        assert int(cnt.item()) == want_n, cap
+        plan.status()
+    rec, cnt, _ = plan.scan_ordered(dev, capacity=want_n)
+    assert acm.synth.device_digest(rec, int(cnt.item())) == (want_n, want_d)
+    ln = rec[:want_n, 1] & 0xFFFFFFFF
+    ok = (rec[1:want_n, 0] > rec[:want_n - 1, 0]) | ((rec[1:want_n, 0] == rec[:want_n - 1, 0]) & (ln[1:] < ln[:-1]))
+    assert bool(ok.all().item())
+    plan.status()
+
+
 def test_dense_matches_everywhere(torch_cuda):
     """Output blow-up: nested keywords matching at every position (queue flush path)."""
     kws = [b"a" * k for k in range(1, 9)] + [b"ab", b"b"]
@@ -1287,11 +1352,21 @@ def _random_case(rng, kind):
         kws = [rng.integers(lo, lo + span, size=rng.integers(1, 14)).astype(np.uint8) for _ in range(int(rng.integers(1, 300)))]
         text = rng.integers(max(lo - 2, 0), min(lo + span + 2, 256), size=int(rng.integers(1, 200000))).astype(np.uint8)
         return kws, text, 1, {}
-    if kind in ("gram", "sticky"):  # small alphabet, > 32768 states, keywords >= 4 symbols
+    if kind in ("gram", "gramold", "sticky"):  # small alphabet, > 32768 states, keywords >= 4 symbols
         span = int(rng.integers(5, 10))
         kws = [rng.integers(97, 97 + span, size=rng.integers(4, 13)).astype(np.uint8) for _ in range(int(rng.integers(11000, 14000)))]
         text = rng.integers(96, 97 + span + 1, size=int(rng.integers(50000, 400000))).astype(np.uint8)
-        return kws, text, 1, ({"ACM_GPU_GRAM": "0"} if kind == "sticky" else {})
+        # gram: scan_gram2_kernel (lane-local sieve, the default for such dictionaries); gramold: scan_gram_kernel
+        return kws, text, 1, ({"ACM_GPU_GRAM": "0"} if kind == "sticky" else ({"ACM_GPU_GRAM2": "0"} if kind == "gramold" else {}))
+    if kind == "gram26":            # the widest alphabet scan_gram2_kernel takes (26 symbols + "other": LDS filled to the last KiB)
+        kws = [rng.integers(97, 123, size=rng.integers(4, 12)).astype(np.uint8) for _ in range(int(rng.integers(9000, 11000)))]
+        text = rng.integers(96, 124, size=int(rng.integers(50000, 400000))).astype(np.uint8)
+        for _ in range(4000):       # keyword heads of 3 to 7 symbols: every stage sees hits and near misses
+            w = kws[int(rng.integers(0, len(kws)))]
+            k = min(w.size, 3 + int(rng.integers(0, 5)))
+            at = int(rng.integers(0, text.size - 12))
+            text[at:at + k] = w[:k]
+        return kws, text, 1, {}
     if kind == "gram30":            # the widest alphabet the exact 4-gram index takes (28-30 classes), Bloom filters on
         lo = int(rng.integers(0, 200)); span = int(rng.integers(27, 30))
         kws = [rng.integers(lo, lo + span, size=rng.integers(4, 10)).astype(np.uint8) for _ in range(int(rng.integers(11000, 13000)))]
@@ -1347,7 +1422,7 @@ def _random_case(rng, kind):
     return kws, text, sym, ({"ACM_GPU_SPARSE": "walk"} if kind.startswith("walk") else {})
 
 
-@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "gramheads", "gram", "gram30", "gramsmall", "wide", "wideshort", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
+@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "gramheads", "gram", "gramold", "gram26", "gram30", "gramsmall", "wide", "wideshort", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
                                        for s in range(int(os.environ.get("ACM_SOAK_SEEDS", "3")))])   # ACM_SOAK_SEEDS=14: a soak run
 def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed):
     """Random dictionaries and texts through every kernel family; whole scans, count-only scans and
@@ -1368,9 +1443,11 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
             text[at:at + w.size] = w
     m, o = build_pair(kws, sym)
     plan = m.plan(0)
-    expect = {"dense": 1, "gramheads": 5, "gram": 5, "gram30": 5, "gramsmall": 5, "wide": 5, "wideshort": 5, "sticky": 1, "short": 5, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
-    if kind in ("gram", "gram30", "wide", "wideshort", "sticky", "short"):
+    expect = {"dense": 1, "gramheads": 5, "gram": 5, "gramold": 5, "gram26": 5, "gram30": 5, "gramsmall": 5, "wide": 5, "wideshort": 5, "sticky": 1, "short": 5, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
+    if kind in ("gram", "gramold", "gram26", "gram30", "wide", "wideshort", "sticky", "short"):
         assert plan.info.dense_rows > 32768, "the generator is meant to give more states than the LDS scheme takes"
+    if kind in ("gram", "gramold", "gram26", "gram30"):
+        assert plan.info.variant == (2 if kind in ("gram", "gram26") else 0), (kind, plan.info.variant)
     if kind == "dense":     # small dictionaries whose hot rows outgrow LDS go to the 4-gram kernel by themselves
         assert plan.info.kernel in (1, 5, 6), plan.info.kernel
     else:
