@@ -48,8 +48,9 @@ wave_incl_scan_dpp (uint32_t v) {
   return v;
 }
 
+constexpr int G2_COMPILER_VGPRS = 104; /* v[104:127]: the four sets of text registers (inline assembly only) */
 template <bool COUNT_ONLY, bool TILED>
-__global__ __launch_bounds__ (SPARSE_THREADS) void
+__global__ __launch_bounds__ (SPARSE_THREADS) __attribute__ ((amdgpu_num_vgpr (G2_COMPILER_VGPRS))) void
 scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
                    uint32_t *fill, RecHole *holes, uint32_t resume, TileEntry *dir, uint32_t dir_base) {
   (void)items;
@@ -119,7 +120,6 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
       w0.prev1 = w0.prev2 = NONE;
     Ws[wib] = w0;
   }
-  const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
   const TileShare share (A);
   const uint32_t last_blk = (A.n - 1) / 16;
   uint32_t qn2 = 0;
@@ -149,9 +149,44 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
   auto lds_word = [&] (uint32_t byte_off) -> uint32_t {
     return *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (byte_off);
   };
-  auto load_group = [&] (uint32_t g) -> uint4 {
+  /* The text of a group in registers: this lane's 16 bytes and the 8 behind them (the next lane's
+   * first; for lane 63 the next group's).  Loaded by inline assembly four groups ahead and waited for
+   * by hand: the compiler cannot count the loads in flight across the pipeline steps' conditional
+   * gathers, so every wait it places on a loop-carried load is s_waitcnt vmcnt(0) -- at the top of
+   * a group that waited for the two gathers the last pipeline step of the group before had JUST
+   * issued, a full L2 / Infinity Cache round trip per group and wave (0.68 of the 2.0 ms a count-only
+   * launch of 2 GiB took).  A set's loads are always followed by those of the three sets behind it
+   * (six operations, vmcnt counts in issue order), so "at most six outstanding" means this set has
+   * landed, whatever else has been issued since -- and leaves the newest gathers in flight.
+   * The four sets live in v[104:127], registers the compiler is told not to allocate
+   * (amdgpu_num_vgpr on the kernel): a value with a load in flight must never be copied, and the
+   * compiler copies values as it likes (with the sets as variables it moved a set to the registers of
+   * an asm operand IN FRONT of the wait).  sieve_group's copies of them are made behind the wait. */
+#define G2_SET_REGS(n) "v" #n
+#define G2_TEXT_ISSUE(M0, M3, T0, T1, c0, c1, c2, c3, c4, c5)                                                              \
+  asm volatile ("global_load_dwordx4 v[" #M0 ":" #M3 "], %0, %2\n\tglobal_load_dwordx2 v[" #T0 ":" #T1 "], %1, %2"           \
+                :: "v"(om), "v"(ot), "s"(text) : "memory", c0, c1, c2, c3, c4, c5)
+#define G2_TEXT_TAKE(M0, M1, M2, M3, T0, T1)                                                                               \
+  asm volatile ("s_waitcnt vmcnt(6)\n\tv_mov_b32 %0, v" #M0 "\n\tv_mov_b32 %1, v" #M1 "\n\tv_mov_b32 %2, v" #M2                \
+                "\n\tv_mov_b32 %3, v" #M3 "\n\tv_mov_b32 %4, v" #T0 "\n\tv_mov_b32 %5, v" #T1                                  \
+                : "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3), "=v"(w4), "=v"(w5) :: "memory")
+  auto issue_text = [&] (const uint32_t set, const uint32_t g) {
     const uint32_t blk = g * WAVE + lane;
-    return text16[blk < last_blk ? blk : last_blk];
+    const uint32_t om = (blk < last_blk ? blk : last_blk) * 16u, ot = (blk + 1 < last_blk ? blk + 1 : last_blk) * 16u;
+    switch (set) { /* (a compile-time constant at every call) */
+    case 0: G2_TEXT_ISSUE (104, 107, 108, 109, "v104", "v105", "v106", "v107", "v108", "v109"); break;
+    case 1: G2_TEXT_ISSUE (110, 113, 114, 115, "v110", "v111", "v112", "v113", "v114", "v115"); break;
+    case 2: G2_TEXT_ISSUE (116, 119, 120, 121, "v116", "v117", "v118", "v119", "v120", "v121"); break;
+    default: G2_TEXT_ISSUE (122, 125, 126, 127, "v122", "v123", "v124", "v125", "v126", "v127"); break;
+    }
+  };
+  auto take_text = [&] (const uint32_t set, uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &w3, uint32_t &w4, uint32_t &w5) {
+    switch (set) {
+    case 0: G2_TEXT_TAKE (104, 105, 106, 107, 108, 109); break;
+    case 1: G2_TEXT_TAKE (110, 111, 112, 113, 114, 115); break;
+    case 2: G2_TEXT_TAKE (116, 117, 118, 119, 120, 121); break;
+    default: G2_TEXT_TAKE (122, 123, 124, 125, 126, 127); break;
+    }
   };
   auto walk_batch = [&] (uint32_t n_items) {
     const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, 2> (Ks, Es, text, q2, qn2, n_items, hits, counted);
@@ -163,6 +198,12 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
   bool st_term = false;
   uint32_t st_pos = 0, st_what = 0;
   auto consume_terminal = [&] () {
+#if defined(ACM_GRAM2_ABLATE) && (ACM_GRAM2_ABLATE == 3 || ACM_GRAM2_ABLATE == 1 || ACM_GRAM2_ABLATE == 8 || ACM_GRAM2_ABLATE == 9) /* experiment: the entries are gathered and only looked at */
+    st_term = false;
+    if (pend_n[0])
+      asm volatile ("" :: "v"(pend_rx[0]), "v"(pend_rw[0]));
+    return;
+#endif
     if (pend_n[0]) {
       /* a keyword of 4 symbols ends here: reported at once, the entry brought its id along */
       st_term = lane < pend_n[0] && (pend_rx[0] >> 31) && pend_item[0].x + 3 >= E.emit_from;
@@ -178,6 +219,9 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
     st_term = false;
   };
   auto consume_pass = [&] () {
+#if defined(ACM_GRAM2_ABLATE) && (ACM_GRAM2_ABLATE == 3 || ACM_GRAM2_ABLATE == 8 || ACM_GRAM2_ABLATE == 9)
+    return;
+#endif
     if (pend_n[0]) {
       const uint32_t c4 = (pend_item[0].y >> 20) & 31u;
       const bool pass = lane < pend_n[0] && ((pend_rx[0] >> c4) & 1u);
@@ -192,6 +236,9 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
           q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 4, K.d5_rel ? (st5 - K.d5_begin) | ((pend_item[0].y >> 25) & 31u) << 24 : st5);
         }
         qn2 = uniform (qn2 + (uint32_t)__popcll (m));
+#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 2 /* experiment: the walk candidates are queued and dropped */
+        qn2 = 0;
+#endif
         while (qn2 >= WAVE)
           walk_batch (WAVE);
       }
@@ -214,8 +261,15 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
     __builtin_amdgcn_sched_barrier (0);
     const uint32_t rank = pend_rx[2] + (pend_ry[2] & ~PEND_NEED);
     uint3 ent = make_uint3 (0, 0, 0);
+#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 9
+    ent = make_uint3 (rank, rank, rank);
+#elif defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 8 /* experiment: every lane asks for the same line */
+    if (pend_n[1] && (pend_ry[2] & PEND_NEED))
+      ent = *reinterpret_cast<const uint3 *> (K.g4entry + 3 * (size_t)(rank & 3u));
+#else
     if (pend_n[1] && (pend_ry[2] & PEND_NEED))
       ent = *reinterpret_cast<const uint3 *> (K.g4entry + 3 * (size_t)rank);
+#endif
     pend_e1 = ent;
     pend_ry[1] = K.d4_begin + rank;
   };
@@ -238,33 +292,40 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
     /* (a lane that needs nothing asks for nothing: a gather costs by the line) */
     const bool need = lane < n_items && ((word >> sh) & 1u) != 0;
     uint32_t pre = 0;
+#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 8
+    if (need)
+      pre = K.prefix2[(idx >> 4) & 15u];
+#elif defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 9 /* experiment: no gathers at all */
+    pre = idx;
+#else
     if (need)
       pre = K.prefix2[idx >> 4];
+#endif
     pend_rx[GRAM_DEPTH - 1] = pre;
     pend_ry[GRAM_DEPTH - 1] = __popc (word & 0x55555555u & ((1u << sh) - 1u)) | (need ? PEND_NEED : 0u);
     emit_stashed ();
     pend_n[GRAM_DEPTH - 1] = n_items;
   };
 
-  /* one group: cur = this lane's 16 bytes, (next_x, next_y) = the first 8 bytes of every lane of the next group */
-  auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t next_y, const uint32_t g, uint4 &prefetched) {
-    /* word 0 of the next lane (v_mov_b32_dpp wave_shl:1; lane 63 keeps `old`: word 0 of the next group's lane 0) */
-    uint32_t after = (uint32_t)__builtin_amdgcn_update_dpp ((int)uniform (next_x), (int)cur.x, 0x130, 0xf, 0xf, false);
-    /* (the group four ahead is asked for behind the first look at this one: scan_gram_kernel) */
-    asm volatile ("" : "+v"(after));
-    __builtin_amdgcn_sched_barrier (0);
-    prefetched = load_group (g + 4);
-    /* the group's text where the lanes that take its survivors off the list find it */
+  /* one group, first half: the sieve.  S holds the group's text (waited for here) and is asked for
+   * the group four ahead as soon as its bytes have become classes; leaves the lane's survivors as
+   * the even bits of `pass`, the number of its first one among the group's in `my`, returns their total */
+  auto sieve_group = [&] (const uint32_t set, const uint32_t g, uint32_t &pass_out, uint32_t &my_out) -> uint32_t {
     typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
     typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
-    *reinterpret_cast<__attribute__ ((address_space (3))) u32x4 *> (stage_off + lane * 16u) = u32x4{ cur.x, cur.y, cur.z, cur.w };
-    if (lane == 0)
-      *reinterpret_cast<__attribute__ ((address_space (3))) u32x2 *> (stage_off + GROUP) = u32x2{ next_x, next_y };
+    uint32_t t0, t1, t2, t3, t4, t5;
+    take_text (set, t0, t1, t2, t3, t4, t5);
+    /* the group's text where the lanes that take its survivors off the list find it */
+    *reinterpret_cast<__attribute__ ((address_space (3))) u32x4 *> (stage_off + lane * 16u) = u32x4{ t0, t1, t2, t3 };
+    if (lane == WAVE - 1)
+      *reinterpret_cast<__attribute__ ((address_space (3))) u32x2 *> (stage_off + GROUP) = u32x2{ t4, t5 };
     const uint32_t pos0 = g * GROUP + lane * 16;
-    const uint32_t w[5] = { cur.x, cur.y, cur.z, cur.w, after };
+    const uint32_t w[5] = { t0, t1, t2, t3, t4 };
 #if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 7 /* experiment: the text is streamed and staged, not looked at */
     asm volatile ("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
-    return;
+    issue_text (set, g + 4);
+    pass_out = 0;
+    return 0;
 #endif
     uint32_t c[20];
 #pragma unroll
@@ -279,6 +340,8 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
         if (pos0 + j >= A.n)
           c[j] = K.span;
     }
+    /* (the set has been copied out: its registers take the group four ahead) */
+    issue_text (set, g + 4);
     uint32_t pair[19];
 #pragma unroll
     for (int j = 0; j < 19; j++)
@@ -302,17 +365,21 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
     const uint32_t ix16 = __umul24 (pair[16], W2) + pair[18];
     const uint32_t h16 = __builtin_amdgcn_ubfe (lds_word ((ix16 >> 4) * 4u), (ix16 << 1) | 1u, 1u);
     /* T (j) and (H (j) or H (j + 1)), at the even bits */
-    uint32_t pass = acc & ((acc >> 1) | (acc >> 3) | (h16 << 30)) & 0x55555555u;
+    const uint32_t pass = acc & ((acc >> 1) | (acc >> 3) | (h16 << 30)) & 0x55555555u;
+    pass_out = pass;
 #if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 6 /* experiment: the sieve alone */
     asm volatile ("" :: "v"(pass));
-    return;
+    return 0;
 #endif
     const uint32_t cnt = __popc (pass);
     const uint32_t incl = wave_incl_scan_dpp (cnt);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane ((int)incl, WAVE - 1);
-    if (total == 0)
-      return;
-    uint32_t my = incl - cnt; /* number of this lane's next survivor among the group's */
+    my_out = incl - cnt;
+    return (uint32_t)__builtin_amdgcn_readlane ((int)incl, WAVE - 1);
+  };
+  /* one group, second half: the survivors listed, their items rebuilt from the staged text, full
+   * batches sent through the pipeline */
+  auto take_group = [&] (const uint32_t g, const uint32_t total, uint32_t pass, uint32_t my) {
+    const uint32_t W2 = K.W * K.W;
     const bool tail = g * GROUP + GROUP + 8 > A.n; /* (the last groups of the segment) */
     for (uint32_t base = 0; base < total; base += G2_LIST) {
       const uint32_t n_here = total - base < G2_LIST ? total - base : G2_LIST;
@@ -422,16 +489,22 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
       W->s_begin = W->s_late = stream_index (*W);
     }
     const uint32_t g0 = tile * K.R;
-    uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
-    for (uint32_t k = 0; k < K.R; k++) {
-      uint4 n3;
+    issue_text (0, g0);
+    issue_text (1, g0 + 1);
+    issue_text (2, g0 + 2);
+    issue_text (3, g0 + 3);
+    for (uint32_t k = 0; k < K.R; k++) { /* (K.R is a multiple of 4: a tile begins with set 0) */
       if (tiled && k + 1 == K.R && lane == 0) /* (keywords are no longer than a group here: what ends beyond the tile starts in its last group) */
         Ws[wib].s_late = stream_index (Ws[wib]);
-      walk_group (c0, c1.x, c1.y, g0 + k, n3);
-      c0 = c1;
-      c1 = c2;
-      c2 = c3;
-      c3 = n3;
+      uint32_t pass = 0, my = 0, total;
+      switch (k & 3u) { /* (four copies of the sieve, one per set of registers; the rest of the group once) */
+      case 0: total = sieve_group (0, g0 + k, pass, my); break;
+      case 1: total = sieve_group (1, g0 + k, pass, my); break;
+      case 2: total = sieve_group (2, g0 + k, pass, my); break;
+      default: total = sieve_group (3, g0 + k, pass, my); break;
+      }
+      if (total)
+        take_group (g0 + k, total, pass, my);
     }
   }
   if (!tiled)
