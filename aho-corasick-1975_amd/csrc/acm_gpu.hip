@@ -399,7 +399,8 @@ struct GramImage {
   bool kw_inline;                          /* keyword ids fit a hit's word (HIT_KW) */
   bool peek_packed;                        /* 4 bytes per depth-5 state (fewer than 2^23 records) instead of 8 */
   uint32_t *g3, *stab;                     /* short keywords: prefix states per 3-gram (narrow) / table of tagged windows (wide) */
-  uint32_t *tab2, *prefix2;                /* scan_gram2_kernel: two bits per 4-gram (GramK::tab2), set even bits in front of each word; NULL: not made */
+  uint32_t *tab2;                          /* scan_gram2_kernel: two bits per 4-gram (GramK::tab2); NULL: not made */
+  uint32_t *rows2, *over2;                 /* the second stage's entries by row of 16 4-grams (GramK::rows2), the rows' 8th and later entries */
 };
 
 void
@@ -474,15 +475,47 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     g4[2 * (size_t)slot] = win;
     g4[2 * (size_t)slot + 1] = st | (fv.term_kw[st] != NONE ? WT_TERM : 0u) | (fv.row_ptr[st + 1] > fv.row_ptr[st] ? WT_KIDS : 0u);
   }
+  uint32_t n_over2 = 0, row_over = 0;
+  std::vector<uint8_t> row_fill (G.rows2 ? (G.W * G.W * G.W * G.W + 15) / 16 : 0, 0); /* (a row has 16 4-grams) */
   for (uint32_t st = fv.depth_start[4]; !G.wide && st < fv.depth_start[5]; st++) {
     const uint32_t idx = path[st];
     uint32_t mask = fv.term_kw[st] != NONE ? 0x80000000u : 0u;
     for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++)
       mask |= 1u << (fv.edge_sym[e] - fi.alpha_lo);
     bits[idx >> 5] |= 1u << (idx & 31);
+    if (G.rows2) {
+      /* the entry of this 4-gram: slot r of its row when it is the r-th (< 7) 4-gram of the row that
+       * exists (the depth-4 states come in ascending index order), else the next entry of the
+       * overflow array, whose first index for the row stands in slot 7 */
+      const uint32_t row = idx >> 4;
+      const uint32_t r = row_fill[row]++;
+      const bool term = fv.term_kw[st] != NONE, kids = fv.row_ptr[st + 1] > fv.row_ptr[st];
+      uint32_t e0 = (mask & 0x3FFFFFFFu) | (term ? 0x80000000u : 0u), e1;
+      if (term && kids) { /* a keyword of 4 symbols that others go on from: left to the walk, at its own record */
+        e0 |= 0x40000000u;
+        e1 = g4gid[st - fv.depth_start[4]];
+      } else
+        e1 = term ? fv.term_kw[st] + G.kw_base : fv.edge_next[fv.row_ptr[st]];
+      if (r < 8) { /* (slot 7: the 8th entry itself while there is no 9th) */
+        G.rows2[16 * (size_t)row + 2 * r] = e0;
+        G.rows2[16 * (size_t)row + 2 * r + 1] = e1;
+      }
+      if (r >= 7) {
+        if (r == 7)
+          row_over = n_over2;
+        if (r == 8) { /* nine or more: slot 7 says where the 8th and later entries are */
+          G.rows2[16 * (size_t)row + 14] = 0x20000000u | row_over;
+          G.rows2[16 * (size_t)row + 15] = 0;
+        }
+        G.over2[2 * (size_t)n_over2] = e0;
+        G.over2[2 * (size_t)n_over2 + 1] = e1;
+        n_over2++;
+      }
+    }
     if (G.tab2) {
       /* T of this 4-gram; H of it when it is a keyword; H of the tails of the 5-grams below it */
-      G.tab2[idx >> 4] |= (fv.term_kw[st] != NONE ? 3u : 1u) << (2 * (idx & 15));
+      const bool term = fv.term_kw[st] != NONE;
+      G.tab2[idx >> 4] |= (term ? 3u : 1u) << (2 * (idx & 15));
       const uint32_t W3 = G.W * G.W * G.W;
       for (uint32_t e = fv.row_ptr[st]; e < fv.row_ptr[st + 1]; e++) {
         const uint32_t tail = (idx % W3) * G.W + (fv.edge_sym[e] - fi.alpha_lo);
@@ -513,11 +546,6 @@ fill_gram_tables (const ACMFlatView &fv, const ACMFlatInfo &fi, const GramImage 
     for (uint32_t w = 0; w < words; w++) {
       G.prefix[w] = acc;
       acc += (uint32_t)__builtin_popcount (bits[w]);
-    }
-    acc = 0;
-    for (uint32_t w = 0; G.tab2 && w < (G.W * G.W * G.W * G.W + 15) / 16; w++) {
-      G.prefix2[w] = acc;
-      acc += (uint32_t)__builtin_popcount (G.tab2[w] & 0x55555555u);
     }
   }
   if (G.shorts && G.wide) {
@@ -790,7 +818,9 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const bool peek_packed = n < (1u << 23) && !(getenv ("ACM_GPU_PEEK8") && atoi (getenv ("ACM_GPU_PEEK8")) == 1);
   const size_t o_g5peek = blob_reserve (cur, gram && !gram_wide ? (size_t)n_depth5 * (peek_packed ? 4 : 8) + 16 : 0);
   const size_t o_tab2 = blob_reserve (cur, gram2 ? (size_t)g2_off + 16 : 0);
-  const size_t o_prefix2 = blob_reserve (cur, gram2 ? (size_t)tab2_words * 4 + 16 : 0);
+  const bool rows2 = gram2; /* (entry words: classes are below 30, bits 30 and 31 are flags) */
+  const size_t o_rows2 = blob_reserve (cur, rows2 ? (size_t)tab2_words * 64 + 16 : 0);
+  const size_t o_over2 = blob_reserve (cur, rows2 ? (size_t)n_depth4 * 8 + 16 : 0);
   p->blob_bytes = cur;
 
   std::vector<unsigned char> host (cur, 0);
@@ -846,7 +876,8 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     G.kw_inline = (uint64_t)fi.n_keywords + kw_base <= HIT_KW_ID;
     G.peek_packed = peek_packed;
     G.tab2 = gram2 ? reinterpret_cast<uint32_t *> (&host[o_tab2]) : nullptr;
-    G.prefix2 = gram2 ? reinterpret_cast<uint32_t *> (&host[o_prefix2]) : nullptr;
+    G.rows2 = rows2 ? reinterpret_cast<uint32_t *> (&host[o_rows2]) : nullptr;
+    G.over2 = rows2 ? reinterpret_cast<uint32_t *> (&host[o_over2]) : nullptr;
     fill_gram_tables (fv, fi, G);
   }
   if (dense) {
@@ -988,10 +1019,14 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
       p->GK.W4 = gW4;
       p->GK.queue_off = bits_bytes;
       p->gram_lds_bytes = bits_bytes + gq + WALK_CTX_BYTES;
+      if (rows2) {
+        p->GK.rows2 = reinterpret_cast<const uint2 *> (b + o_rows2);
+        p->GK.over2 = reinterpret_cast<const uint2 *> (b + o_over2);
+      }
       if (gram2) {
         p->gram2 = true;
         p->GK.tab2 = u32p (o_tab2);
-        p->GK.prefix2 = u32p (o_prefix2);
+
         p->GK.tab2_words = tab2_words;
         p->GK.g2_off = g2_off;
         p->gram_lds_bytes = g2_off + G2_LDS_FIXED;

@@ -78,10 +78,23 @@ struct GramK {
   uint32_t queue_off;     /* LDS: [g4 bits][16 x first queue][16 x second queue][16 x hit buffer][tile counter] */
   /* scan_gram2_kernel (dev_gram2.h): two bits per 4-gram, staged in LDS -- bit 2i: "a keyword starts
    * with 4-gram i" (the same as g4bits), bit 2i + 1: "4-gram i is a keyword, or the tail (symbols
-   * 2-5) of some keyword's first five"; prefix2[w] = set even bits in front of word w (the rank of
-   * a depth-4 state); g2_off: LDS offset of the waves' areas behind the table.  tab2 == NULL: the
-   * plan does not use that kernel. */
-  const uint32_t *tab2, *prefix2;
+   * 2-5) of some keyword's first five"; g2_off: LDS offset of the waves' areas behind the table.
+   * tab2 == NULL: the plan does not use that kernel.
+   * rows2 (scan_gram2_kernel): what the second stage needs of an existing
+   * 4-gram, ONE 64-byte line per 16 4-grams: slot r < 7 = the entry of the r-th 4-gram of the 16
+   * that exists, {children mask | "goes on as well" << 30 | keyword << 31, x} with x = the
+   * keyword's id (a keyword that does not go on), the first child's state id (no keyword), or the
+   * record of the depth-4 state itself (a keyword of 4 symbols that other keywords go on from: 2 %
+   * of config 3's 4-grams -- such a position becomes a walk item AT that record, which reports the
+   * keyword and goes on: nothing else has to be fetched for it); slot 7 = the 8th entry, or, when there
+   * are nine or more, {1 << 29 | index into over2 of the 8th entry, -} (one line in 600 of config
+   * 3's: the dependent gather it costs is exposed, so it must be rare per BATCH).  One gather per survivor
+   * instead of two dependent ones (prefix count, then entry by rank: scan_gram_kernel keeps those --
+   * with its Bloom filters in front, 5.5 % of the positions gather instead of 7.4 %, and the rows
+   * measured SLOWER there: count-only 1.87 -> 2.33 ms per 2 GiB of config 3; the 2.1 MB of rows miss
+   * L2 more often than the 66 KB + 1 MB of the tables by rank). */
+  const uint32_t *tab2;
+  const uint2 *rows2, *over2;
   uint32_t tab2_words, g2_off;
 };
 

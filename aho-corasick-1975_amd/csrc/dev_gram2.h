@@ -132,20 +132,11 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
   /* the batch that is being put together: lanes [0, pk) hold an item (position, 4-gram index |
    * class of the 5th symbol << 20 | class of the 6th << 25) */
   uint32_t it_x = 0, it_y = 0, pk = 0;
-  /* batches whose gathers are in flight: scan_gram_kernel's pipeline (slot 2: prefix count asked
-   * for + rank inside the word | NEED; slot 1: the entry; slot 0: looked at next) */
-  constexpr int GRAM_DEPTH = 3;
-  uint2 pend_item[GRAM_DEPTH];
-  uint32_t pend_rx[GRAM_DEPTH], pend_ry[GRAM_DEPTH], pend_rz[1] = { 0 }, pend_rw[1] = { 0 };
-  uint3 pend_e1 = make_uint3 (0, 0, 0);
-  uint32_t pend_n[GRAM_DEPTH];
+  /* the batch whose gather is in flight: its items, the entry every lane asked for (landing), the
+   * number of existing 4-grams in front of the lane's in its word | NEED, the number of items */
+  uint2 pend_item = make_uint2 (0, 0), pend_e = make_uint2 (0, 0);
+  uint32_t pend_r = 0, pend_n = 0;
   constexpr uint32_t PEND_NEED = 0x80000000u;
-#pragma unroll
-  for (int d = 0; d < GRAM_DEPTH; d++) {
-    pend_item[d] = make_uint2 (0, 0);
-    pend_rx[d] = pend_ry[d] = 0;
-    pend_n[d] = 0;
-  }
   auto lds_word = [&] (uint32_t byte_off) -> uint32_t {
     return *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (byte_off);
   };
@@ -195,116 +186,83 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
     if (!COUNT_ONLY)
       rs = rec_state_load (hits); /* (the walk may have gone on to the next chunk) */
   };
-  bool st_term = false;
-  uint32_t st_pos = 0, st_what = 0;
-  auto consume_terminal = [&] () {
-#if defined(ACM_GRAM2_ABLATE) && (ACM_GRAM2_ABLATE == 3 || ACM_GRAM2_ABLATE == 1 || ACM_GRAM2_ABLATE == 8 || ACM_GRAM2_ABLATE == 9) /* experiment: the entries are gathered and only looked at */
-    st_term = false;
-    if (pend_n[0])
-      asm volatile ("" :: "v"(pend_rx[0]), "v"(pend_rw[0]));
+  /* The batch in flight is looked at: a keyword of 4 symbols ends here (reported at once: the
+   * entry brought its id along); the 5th symbol is an edge of the depth-4 state (a walk candidate
+   * at the depth-5 state it leads to, the class of the 6th symbol riding along: the walk's first
+   * look needs no text). */
+  auto consume_pending = [&] () {
+    if (pend_n == 0)
+      return;
+    /* (words, not a struct: a uint2 assigned under a condition was put in scratch memory) */
+    struct { uint32_t x, y; } e = { pend_e.x, pend_e.y };
+    const bool valid = lane < pend_n && (pend_r & PEND_NEED) != 0;
+    const uint32_t r = pend_r & 0xFFu;
+#if defined(ACM_GRAM2_ABLATE) && (ACM_GRAM2_ABLATE == 3 || ACM_GRAM2_ABLATE == 8) /* experiment: the entries are gathered and only looked at */
+    asm volatile ("" :: "v"(e.x), "v"(e.y));
+    pend_n = 0;
     return;
 #endif
-    if (pend_n[0]) {
-      /* a keyword of 4 symbols ends here: reported at once, the entry brought its id along */
-      st_term = lane < pend_n[0] && (pend_rx[0] >> 31) && pend_item[0].x + 3 >= E.emit_from;
-      st_pos = pend_item[0].x + 3;
-      st_what = pend_rw[0];
-    } else
-      st_term = false;
-  };
-  auto emit_stashed = [&] () {
-    emit_terminals<COUNT_ONLY, true> (E, st_term, st_pos, st_what, 4u, lane, hits, counted, Es, &rs);
+    /* (rare: the word has nine entries or more -- slot 7 says where the 8th and later ones are) */
+    const bool far = valid && r >= 7 && (e.x & 0x20000000u) != 0;
+    if (__ballot (far)) {
+      const uint2 o = K.over2[far ? (e.x & 0x1FFFFFFFu) + (r - 7) : 0u];
+      e.x = far ? o.x : e.x;
+      e.y = far ? o.y : e.y;
+    }
+    if (!valid)
+      e.x = 0;
+    /* a keyword of 4 symbols that other keywords go on from is left to the walk: an item at the
+     * depth-4 state's own record, which reports it and looks at the 5th symbol itself */
+    const bool at_record = (e.x & 0x40000000u) != 0;
+#if !(defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 1)
+    emit_terminals<COUNT_ONLY, true> (E, (e.x >> 31) != 0 && !at_record && pend_item.x + 3 >= E.emit_from, pend_item.x + 3, e.y, 4u, lane, hits, counted, Es, &rs);
     if (!COUNT_ONLY)
       counted = uniform ((uint32_t)counted);
-    st_term = false;
-  };
-  auto consume_pass = [&] () {
-#if defined(ACM_GRAM2_ABLATE) && (ACM_GRAM2_ABLATE == 3 || ACM_GRAM2_ABLATE == 8 || ACM_GRAM2_ABLATE == 9)
-    return;
 #endif
-    if (pend_n[0]) {
-      const uint32_t c4 = (pend_item[0].y >> 20) & 31u;
-      const bool pass = lane < pend_n[0] && ((pend_rx[0] >> c4) & 1u);
-      const uint64_t m = __ballot (pass);
-      if (m) {
-        /* (a walk call handles one level of the newest items and never leaves more than it took,
-         * and every item ends within lmax levels) */
-        while (qn2 + (uint32_t)__popcll (m) > G2_Q2)
-          walk_batch (qn2 < WAVE ? qn2 : WAVE);
-        if (pass) { /* the depth-5 state, at the 5th symbol; the 6th symbol's class rides along (the walk's first look needs no text) */
-          const uint32_t st5 = pend_rz[0] + __popc (pend_rx[0] & ((1u << c4) - 1u));
-          q2[qn2 + rank_below (m)] = make_uint2 (pend_item[0].x + 4, K.d5_rel ? (st5 - K.d5_begin) | ((pend_item[0].y >> 25) & 31u) << 24 : st5);
-        }
-        qn2 = uniform (qn2 + (uint32_t)__popcll (m));
-#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 2 /* experiment: the walk candidates are queued and dropped */
-        qn2 = 0;
-#endif
-        while (qn2 >= WAVE)
-          walk_batch (WAVE);
+    const uint32_t c4 = (pend_item.y >> 20) & 31u;
+    const bool pass = ((e.x >> c4) & 1u) != 0 || at_record; /* (classes are below 30: never one of the two flag bits) */
+    const uint64_t m = __ballot (pass);
+    if (m) {
+      /* (a walk call handles one level of the newest items and never leaves more than it took,
+       * and every item ends within lmax levels) */
+      while (qn2 + (uint32_t)__popcll (m) > G2_Q2)
+        walk_batch (qn2 < WAVE ? qn2 : WAVE);
+      if (pass) {
+        const uint32_t st5 = e.y + __popc (e.x & ((1u << c4) - 1u));
+        q2[qn2 + rank_below (m)] = at_record ? make_uint2 (pend_item.x + 3, e.y | WI_RECORD | (K.d5_rel ? c4 << 24 : 0u))
+                                             : make_uint2 (pend_item.x + 4, K.d5_rel ? (st5 - K.d5_begin) | ((pend_item.y >> 25) & 31u) << 24 : st5);
       }
-    }
-  };
-  auto pipeline_shift = [&] () {
-    pend_item[0] = pend_item[1];
-    pend_ry[0] = pend_ry[1];
-    pend_n[0] = pend_n[1];
-    pend_item[1] = pend_item[2];
-    pend_n[1] = pend_n[2];
-    pend_n[2] = 0;
-    /* the middle batch's entries came in one 12-byte gather (a register tuple: it stays where it
-     * landed until its words are copied out here, one step later) */
-    pend_rx[0] = pend_e1.x;
-    pend_rz[0] = pend_e1.y;
-    pend_rw[0] = pend_e1.z;
-    asm volatile ("" : "+v"(pend_rx[0]), "+v"(pend_ry[0]), "+v"(pend_rz[0]), "+v"(pend_rw[0]), "+v"(pend_item[0].x), "+v"(pend_item[0].y),
-                  "+v"(pend_item[1].x), "+v"(pend_item[1].y));
-    __builtin_amdgcn_sched_barrier (0);
-    const uint32_t rank = pend_rx[2] + (pend_ry[2] & ~PEND_NEED);
-    uint3 ent = make_uint3 (0, 0, 0);
-#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 9
-    ent = make_uint3 (rank, rank, rank);
-#elif defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 8 /* experiment: every lane asks for the same line */
-    if (pend_n[1] && (pend_ry[2] & PEND_NEED))
-      ent = *reinterpret_cast<const uint3 *> (K.g4entry + 3 * (size_t)(rank & 3u));
-#else
-    if (pend_n[1] && (pend_ry[2] & PEND_NEED))
-      ent = *reinterpret_cast<const uint3 *> (K.g4entry + 3 * (size_t)rank);
+      qn2 = uniform (qn2 + (uint32_t)__popcll (m));
+#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 2 /* experiment: the walk candidates are queued and dropped */
+      qn2 = 0;
 #endif
-    pend_e1 = ent;
-    pend_ry[1] = K.d4_begin + rank;
+      while (qn2 >= WAVE)
+        walk_batch (WAVE);
+    }
+    pend_n = 0;
   };
-  auto consume_oldest = [&] () {
-    consume_terminal ();
-    emit_stashed ();
-    consume_pass ();
-    pipeline_shift ();
-  };
-  /* One pipeline step: the oldest batch is consumed, the n items in lanes [0, n) of (it_x, it_y)
-   * take the slot that frees up and send for their prefix counts. */
+  /* One step: the batch in flight is looked at, the n items in lanes [0, n) of (it_x, it_y) send
+   * for their entries -- the word of the table says which slot of the word's line is theirs. */
   auto batch_step = [&] (uint32_t n_items) {
-    consume_terminal ();
     const uint32_t idx = it_y & 0xFFFFFu;
     const uint32_t word = lds_word ((idx >> 4) * 4u);
-    consume_pass ();
-    pipeline_shift ();
-    pend_item[GRAM_DEPTH - 1] = make_uint2 (it_x, it_y);
+    consume_pending ();
     const uint32_t sh = (idx & 15u) * 2u;
     /* (a lane that needs nothing asks for nothing: a gather costs by the line) */
     const bool need = lane < n_items && ((word >> sh) & 1u) != 0;
-    uint32_t pre = 0;
-#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 8
+    const uint32_t r = __popc (word & 0x55555555u & ((1u << sh) - 1u));
+    uint2 e = make_uint2 (0, 0);
+#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 8 /* experiment: every lane asks for the same line */
     if (need)
-      pre = K.prefix2[(idx >> 4) & 15u];
-#elif defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 9 /* experiment: no gathers at all */
-    pre = idx;
+      e = K.rows2[r < 7 ? r : 7];
 #else
     if (need)
-      pre = K.prefix2[idx >> 4];
+      e = K.rows2[(size_t)(idx >> 4) * 8 + (r < 7 ? r : 7)];
 #endif
-    pend_rx[GRAM_DEPTH - 1] = pre;
-    pend_ry[GRAM_DEPTH - 1] = __popc (word & 0x55555555u & ((1u << sh) - 1u)) | (need ? PEND_NEED : 0u);
-    emit_stashed ();
-    pend_n[GRAM_DEPTH - 1] = n_items;
+    pend_e = e;
+    pend_item = make_uint2 (it_x, it_y);
+    pend_r = r | (need ? PEND_NEED : 0u);
+    pend_n = n_items;
   };
 
   /* one group, first half: the sieve.  S holds the group's text (waited for here) and is asked for
@@ -452,9 +410,7 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
       batch_step (pk);
       pk = 0;
     }
-#pragma unroll
-    for (int d = 0; d < GRAM_DEPTH; d++)
-      consume_oldest ();
+    consume_pending ();
     while (qn2)
       walk_batch (qn2 < WAVE ? qn2 : WAVE);
   };

@@ -91,9 +91,13 @@ __device__ __forceinline__ void
 flush_hits (const EmitCtx &E, uint2 *hits, uint32_t n, uint32_t lane) {
   const uint2 rp = hits[-2], cf = hits[-1];
   if (cf.y + n <= cf.x) {
-    uint2 *region = reinterpret_cast<uint2 *> (((uint64_t)rp.y << 32) | rp.x);
-    if (lane < n)
-      region[cf.y + lane] = hits[lane];
+    /* (a global store, not a flat one through a generic pointer: see emit_terminals) */
+    typedef uint32_t g_u32x2 __attribute__ ((ext_vector_type (2)));
+    const uint64_t region = ((uint64_t)rp.y << 32) | rp.x;
+    if (lane < n) {
+      const uint2 h = hits[lane];
+      *reinterpret_cast<__attribute__ ((address_space (1))) g_u32x2 *> (region + (uint64_t)(cf.y + lane) * 8u) = g_u32x2{ h.x, h.y };
+    }
     if (lane == 0)
       hits[-1] = make_uint2 (cf.x, cf.y + n);
     return;
@@ -473,7 +477,11 @@ emit_terminals (const EmitCtx &E, bool hit, uint32_t p, uint32_t kw, uint32_t le
           u32x4 v = { (uint32_t)gp, (uint32_t)(gp >> 32), length, kw };
           __builtin_nontemporal_store (v, reinterpret_cast<u32x4 *> (reinterpret_cast<unsigned char *> (here.dst) + off));
 #else
-          *reinterpret_cast<uint4 *> (reinterpret_cast<unsigned char *> (here.dst) + off) = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), length, kw);
+          /* (a GLOBAL store: through a generic pointer -- the chunk's address comes out of LDS as two
+           * integers -- the compiler emits flat_store, which counts on lgkmcnt as well, and every LDS
+           * read behind it then waits until the store has been acknowledged by L2) */
+          typedef uint32_t g_u32x4 __attribute__ ((ext_vector_type (4)));
+          *reinterpret_cast<__attribute__ ((address_space (1))) g_u32x4 *> (here.dst + off) = g_u32x4{ (uint32_t)gp, (uint32_t)(gp >> 32), length, kw };
 #endif
         }
         tally = hn + total;
