@@ -12,6 +12,8 @@ RECORD_DTYPE = np.dtype([("end_pos", "<u8"), ("length", "<u4"), ("keyword_id", "
 
 ACM_GPU_OK = 0
 ACM_GPU_E_INELIGIBLE = -1
+ACM_GPU_E_NODEVICE = -2
+ACM_GPU_E_HIP = -3
 ACM_GPU_E_OVERFLOW = -4
 ACM_GPU_E_ARG = -5
 
@@ -78,7 +80,7 @@ EXPORTS = [
     "acm_gpu_plan_timing_read", "acm_gpu_plan_timing_read_all", "acm_gpu_plan_status", "acm_gpu_synth_text",
     "acm_gpu_stream_open", "acm_gpu_stream_feed", "acm_gpu_stream_finish", "acm_gpu_stream_close",
     "acm_gpu_multi_create", "acm_gpu_multi_destroy", "acm_gpu_multi_shard_bounds", "acm_gpu_multi_scan_host",
-    "acm_gpu_multi_scan_device",
+    "acm_gpu_multi_scan_device", "acm_set_symbol_bytes", "acm_scan_path",
 ]
 
 
@@ -178,6 +180,10 @@ def lib():
     L.acm_gpu_scan_host.argtypes = [vp, vp, u64, u64, u64, vp, u64, C.POINTER(u64)]
     L.acm_scan.restype = i32
     L.acm_scan.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    L.acm_set_symbol_bytes.restype = i32
+    L.acm_set_symbol_bytes.argtypes = [vp, C.c_uint32]
+    L.acm_scan_path.restype = i32
+    L.acm_scan_path.argtypes = [vp]
     L.acm_gpu_stream_open.restype = i32
     L.acm_gpu_stream_open.argtypes = [vp, u64, u64, C.POINTER(vp)]
     L.acm_gpu_stream_feed.restype = i32
@@ -442,14 +448,24 @@ class Machine:
         _check(self.L.acm_gpu_plan_create_classes(self.handle, self.sym_size, device, C.byref(h)), "acm_gpu_plan_create_classes")
         return Plan(h, self.sym_size)
 
+    def set_symbol_bytes(self, sym_bytes):
+        """acm_set_symbol_bytes(): the symbol size of a machine with a comparator of its own."""
+        _check(self.L.acm_set_symbol_bytes(self.handle, sym_bytes), "acm_set_symbol_bytes")
+
+    @property
+    def scan_path(self):
+        """acm_scan_path(): 1 GPU, 2 GPU over comparator classes, 3 the caller loop on the host, 0 none yet."""
+        return int(self.L.acm_scan_path(self.handle))
+
     def scan_host(self, text, capacity=None):
-        """acm_scan(): host buffers in, canonical records out (GPU inside)."""
-        t = self._symbols(text)
+        """acm_scan(): host buffers in, canonical records out (GPU inside; the host loop for machines
+        the GPU cannot take by their nature: scan_path says which)."""
+        t = np.ascontiguousarray(text) if self.sym_size not in _SYM_DTYPE else self._symbols(text)
         cap = int(capacity) if capacity is not None else max(1024, t.size // 64)
         while True:
             out = np.zeros(cap, dtype=RECORD_DTYPE)
             n = C.c_uint64(0)
-            rc = self.L.acm_scan(self.handle, t.ctypes.data, t.size, out.ctypes.data, cap, C.byref(n))
+            rc = self.L.acm_scan(self.handle, t.ctypes.data, t.size * t.itemsize // self.sym_size, out.ctypes.data, cap, C.byref(n))
             if rc == ACM_GPU_E_OVERFLOW and capacity is None:
                 cap = int(n.value)
                 continue

@@ -3320,10 +3320,39 @@ extern "C" int
 acm_scan (ACMachine *machine, const void *text, uint64_t n_symbols, ACMRecord *records, uint64_t capacity, uint64_t *n_found) {
   if (!machine || !n_found)
     return ACM_GPU_E_ARG;
+  /* which path (include/acm_gpu.h): ACM_CMP_DEFAULT over 1/2/4/8 bytes -> GPU; another comparator
+   * with its symbol size declared -> GPU over its classes (1/2/4 bytes) or the caller loop on the host */
+  uint32_t own_bytes = 0;
+  const bool plain = acm_internal_symbol_bytes (machine, &own_bytes) == ACM_GPU_OK;
+  uint32_t said = acm_internal_declared_symbol_bytes (machine);
+  if (!plain && said == 0) {
+    /* (ACM_CMP_DEFAULT over symbols of another size says the size itself: memcmp's length) */
+    CMP_TYPE cmp = nullptr;
+    void *cmp_arg = nullptr;
+    acm_internal_comparator (machine, &cmp, &cmp_arg);
+    if (cmp == ACM_CMP_DEFAULT && cmp_arg && *static_cast<const size_t *> (cmp_arg) > 0 && *static_cast<const size_t *> (cmp_arg) <= 4096)
+      said = (uint32_t)*static_cast<const size_t *> (cmp_arg);
+  }
+  if (!plain && said == 0)
+    return ACM_GPU_E_INELIGIBLE;
+  bool classes = !plain && (said == 1 || said == 2 || said == 4);
+  {
+    CMP_TYPE cmp = nullptr;
+    void *cmp_arg = nullptr;
+    acm_internal_comparator (machine, &cmp, &cmp_arg);
+    if (cmp == ACM_CMP_DEFAULT)
+      classes = false; /* (memcmp over 3, 5, ... bytes: no classes to enumerate, the loop itself) */
+  }
   acm_internal_plan_lock (machine);
+  int rc = ACM_GPU_OK;
+  if (!plain && !classes) {
+    rc = acm_internal_cpu_scan (machine, text, n_symbols, said, records, capacity, n_found);
+    acm_internal_set_scan_path (machine, ACM_SCAN_PATH_CPU_LOOP);
+    acm_internal_plan_unlock (machine);
+    return rc;
+  }
   void **slot = acm_internal_plan_slot (machine);
   ACMPlan *plan = static_cast<ACMPlan *> (*slot);
-  int rc = ACM_GPU_OK;
   if (plan && (plan->generation != acm_internal_generation (machine) ||
                (plan->delta && plan->delta_scanned > (uint64_t)(plan->finfo.n_keywords > 1000 ? plan->finfo.n_keywords : 1000) * (14ull << 20))))
     rc = acm_gpu_plan_update (plan, machine); /* new keywords, or a delta that has cost more second passes than one plan of everything */
@@ -3334,14 +3363,24 @@ acm_scan (ACMachine *machine, const void *text, uint64_t n_symbols, ACMRecord *r
     /* keywords inserted while the tables are being made are picked up by the next call: the
      * generation is read first */
     const uint64_t gen = acm_internal_generation (machine);
-    rc = acm_gpu_plan_create (machine, device, &plan);
+    rc = classes ? acm_gpu_plan_create_classes (machine, said, device, &plan) : acm_gpu_plan_create (machine, device, &plan);
     if (!rc) {
       plan->generation = gen;
       *slot = plan;
     }
   }
-  if (!rc)
+  if (rc == ACM_GPU_E_INELIGIBLE && classes) {
+    /* the comparator is no consistent order over all symbol values (acm_flatten_classes): the GPU
+     * cannot take this machine by its nature -- the loop itself */
+    rc = acm_internal_cpu_scan (machine, text, n_symbols, said, records, capacity, n_found);
+    acm_internal_set_scan_path (machine, ACM_SCAN_PATH_CPU_LOOP);
+    acm_internal_plan_unlock (machine);
+    return rc;
+  }
+  if (!rc) {
     rc = acm_gpu_scan_host (plan, text, n_symbols, 0, 0, records, capacity, n_found);
+    acm_internal_set_scan_path (machine, classes ? ACM_SCAN_PATH_GPU_CLASSES : ACM_SCAN_PATH_GPU);
+  }
   acm_internal_plan_unlock (machine);
   return rc;
 }

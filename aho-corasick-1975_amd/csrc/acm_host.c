@@ -67,6 +67,8 @@ struct _ac_machine {
   struct _ac_state **keywords; /* keyword_id -> terminal state (acm_get_keyword) */
   size_t keywords_cap;
   int stale; /* ACM_NMEYER_85: failure links and output counts await the breadth-first pass */
+  uint32_t declared_sym_bytes; /* acm_set_symbol_bytes: symbol size of a machine with a comparator of its own (0: not said) */
+  int scan_path;               /* acm_scan_path: what the last acm_scan on this machine ran */
 };
 
 void (*acm_internal_plan_dropper) (void *plan) = 0;
@@ -106,6 +108,32 @@ acm_internal_symbol_bytes (const ACMachine *m, uint32_t *sym_bytes) {
   *sym_bytes = (uint32_t)sz;
   return ACM_GPU_OK;
 }
+/* include/acm_gpu.h: the symbol size of a machine whose comparator is not ACM_CMP_DEFAULT (the
+ * library cannot know it: letters are opaque pointers, aho_corasick.h:33-43) -- what acm_scan
+ * needs to step through a buffer */
+int
+acm_set_symbol_bytes (ACMachine *machine, uint32_t sym_bytes) {
+  if (!machine || sym_bytes == 0 || sym_bytes > 4096)
+    return ACM_GPU_E_ARG;
+  uint32_t own = 0;
+  if (acm_internal_symbol_bytes (machine, &own) == ACM_GPU_OK && own != sym_bytes)
+    return ACM_GPU_E_ARG; /* ACM_CMP_DEFAULT says it itself */
+  machine->declared_sym_bytes = sym_bytes;
+  return ACM_GPU_OK;
+}
+uint32_t
+acm_internal_declared_symbol_bytes (const ACMachine *m) {
+  return m->declared_sym_bytes;
+}
+int
+acm_scan_path (const ACMachine *machine) {
+  return machine ? machine->scan_path : ACM_SCAN_PATH_NONE;
+}
+void
+acm_internal_set_scan_path (ACMachine *m, int path) {
+  m->scan_path = path;
+}
+
 void
 acm_internal_comparator (const ACMachine *m, CMP_TYPE *cmp, void **cmp_arg) {
   *cmp = m->cmp;
@@ -661,4 +689,39 @@ acm_print (ACMachine *machine, FILE *stream, PRINT_TYPE printer) {
   fprintf (stream, "\n");
   print_subtree (machine->root, stream, &col, 0, printer);
   fprintf (stream, "\n");
+}
+
+/* The reference's caller loop (examples/test.c:17-23; acm_match aho_corasick.c:434-448, acm_get_match
+ * :451-482) over a buffer of fixed-size symbols, with THIS library's own automaton step and failure
+ * chain -- what acm_scan runs for a machine the GPU path cannot take (a comparator of its own over
+ * symbols that are not 1, 2 or 4 bytes wide, or one that is no consistent order over all values:
+ * SURVEY.md 8b).  Records in the loop's order; *n_found = their total, also beyond `capacity`. */
+int
+acm_internal_cpu_scan (ACMachine *m, const void *text, uint64_t n_symbols, uint32_t sym_bytes, ACMRecord *records, uint64_t capacity,
+                       uint64_t *n_found) {
+  if (!m || !n_found || (n_symbols && !text) || (capacity && !records) || !sym_bytes)
+    return ACM_GPU_E_ARG;
+#ifdef ACM_NMEYER_85
+  acm_internal_refresh (m);
+#endif
+  const unsigned char *t = text;
+  const struct _ac_state *s = m->root;
+  uint64_t found = 0;
+  for (uint64_t i = 0; i < n_symbols; i++) {
+    s = automaton_step (s, t + i * sym_bytes);
+    uint32_t nb = LOAD (&s->nb_outputs);
+    for (const struct _ac_state *o = s; nb; o = LOAD (&o->fail)) { /* nearest (= longest) terminal state first */
+      if (!LOAD (&o->terminal))
+        continue;
+      if (found < capacity) {
+        records[found].end_pos = i;
+        records[found].length = o->depth;
+        records[found].keyword_id = o->rank;
+      }
+      found++;
+      nb--;
+    }
+  }
+  *n_found = found;
+  return found > capacity ? ACM_GPU_E_OVERFLOW : ACM_GPU_OK;
 }

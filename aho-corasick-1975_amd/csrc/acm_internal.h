@@ -51,6 +51,11 @@ uint32_t acm_internal_nb_states (const ACMachine *m);
 /* 0 if the machine uses ACM_CMP_DEFAULT over 1, 2 or 4 byte symbols, else ACM_GPU_E_INELIGIBLE */
 int acm_internal_symbol_bytes (const ACMachine *m, uint32_t *sym_bytes);
 void acm_internal_comparator (const ACMachine *m, CMP_TYPE *cmp, void **cmp_arg);
+/* acm_set_symbol_bytes' value (0: none); the caller loop on the host for machines the GPU cannot take; acm_scan_path's value */
+uint32_t acm_internal_declared_symbol_bytes (const ACMachine *m);
+int acm_internal_cpu_scan (ACMachine *m, const void *text, uint64_t n_symbols, uint32_t sym_bytes, ACMRecord *records, uint64_t capacity,
+                           uint64_t *n_found);
+void acm_internal_set_scan_path (ACMachine *m, int path);
 /* ACM_NMEYER_85 builds: brings failure links and output counts up to date (no-op otherwise);
  * takes the machine lock itself */
 void acm_internal_refresh (ACMachine *m);

@@ -6,28 +6,56 @@
  * scan_gram_kernel (dev_gram.h) asks one LDS bit per position -- "a keyword starts with this
  * 4-gram", 19.6 % of config 3's positions -- and pushes the survivors into a per-wave queue position
  * by position: ballot -> scalar count -> branch -> LDS write, 21 instructions in one dependent
- * chain per position and wave, 0.42 of the 1.85 ms a count-only launch of 2 GiB takes, and the
- * batches that empty the queue (Bloom filters in front of the rank gathers) another 0.47.  Here:
+ * chain per position and wave, and empties the queue in batches with Bloom filters in front of
+ * two dependent gathers by rank.  Here:
  *   1. two bits per 4-gram in LDS, T = "a keyword starts with it" and H = "it IS a keyword of 4
  *      symbols, or it is the TAIL (symbols 2-5) of some keyword's first five".  A position can
  *      only have something to report if T (p) and (H (p) or H (p + 1)) -- its 4-gram is a keyword,
- *      or its 5-gram can be a prefix: 7.4 % of config 3's positions instead of 19.6 %, for the
- *      same one LDS word per position (the word of position p + 1 is read for p + 1 anyway).  No
- *      Bloom filters: what is left is few enough to go straight to the rank gathers;
+ *      or its 5-gram can be a prefix: 8.7 % of config 3's positions (3.2 % real) instead of 19.6 %,
+ *      for the same one LDS word per position (the word of position p + 1 is read for p + 1
+ *      anyway).  No Bloom filters: LDS has nothing left for them;
  *   2. a lane keeps the answers of its 16 positions as bits of ONE register (one v_bfe + one
  *      v_lshl_or per position, no ballot, no scalar instruction, no branch); per group of 1,024
- *      positions one wave-wide prefix sum (DPP) says where every lane's survivors go, and the lanes
- *      write their POSITIONS (2 bytes each) side by side into a list in LDS;
+ *      positions one wave-wide prefix sum (six DPP adds) says where every lane's survivors go, and
+ *      the lanes write their POSITIONS (2 bytes each) side by side into a list in LDS;
  *   3. the group's text is staged in LDS (one ds_write_b128 per lane), so the lane that takes
  *      survivor number s off the list rebuilds its item -- 4-gram index, classes of the 5th and
  *      6th symbol -- from six bytes at a run-time LDS address (not a run-time register index);
- *      batches of 64 are assembled in registers across groups and go through the same pipeline
- *      of two dependent gathers (rank, then entry), terminal reports and walks as in
- *      scan_gram_kernel.
+ *      batches of 64 are put together in registers across groups;
+ *   4. ONE gather per survivor: its entry {children mask | flags, keyword id or first child} from
+ *      the 64-byte line of its 16 4-grams (GramK::rows2), asked for in one step and looked at in
+ *      the next; a keyword of 4 symbols is reported on the spot, a 5th symbol that goes on becomes
+ *      a walk candidate whose first look (the peek entry of its depth-5 state) is asked for in the
+ *      same way, a step ahead -- only what passes it (1 in 26) reaches walk_starts.
  * LDS: 2 x W^4 bits (a-z + "other": 132,864 B) + per wave 1,040 B of staged text, 256 B of list and
  * a walk queue of 64 items; alphabets of up to 26 symbols fit.  Everything else (tiles, records
  * written by the wave itself into chunks of the caller's buffer, tiled scans with a directory,
- * resumed segments) is scan_gram_kernel's. */
+ * resumed segments) is scan_gram_kernel's.
+ *
+ * Measured on config 3, 2 GiB per launch, both kernels in one process (tools/exp_gram2.py): records
+ * 2.34 -> 1.98 ms, count only 1.85 -> 1.60, tiled 2.43 -> 2.15.  What the cycle stamps of a
+ * diagnostic build (tools/diag_gram2.py) say of a wave's 7,300 cycles per group: sieve 1,800, list
+ * and rebuild 2,700, entries looked at 1,000, walks 500 to 1,200, waits for the gathers ~100 --
+ * four waves per SIMD (one block per CU: the table fills LDS) and a chain of LDS round trips per
+ * group; the SIMD issues ~600 instructions per group and wave.
+ * Tried on the way, measured, not kept:
+ *   - the entry by RANK as scan_gram_kernel has it (prefix count of the word, then entry: two
+ *     dependent gathers, 406 M requests to L2 per launch): same time within 2 % once nothing sat
+ *     in scratch memory -- a uint2 assigned under a condition did, two scratch stores and two
+ *     flat loads per step, +0.5 ms, found as SQ_INSTS_VMEM_RD going UP when a gather was removed;
+ *   - the rows in scan_gram_kernel (its Bloom filters leave 5.5 % of the positions to gather):
+ *     count only 1.87 -> 2.33 ms -- the 2.1 MB of rows miss L2 more often than its 66 KB + 1 MB;
+ *   - the text in four fixed sets of registers loaded by inline assembly with a counted wait
+ *     (s_waitcnt vmcnt(6) at the top of a group instead of the compiler's vmcnt(0), which also
+ *     waits for the gathers the last step has just issued): the registers have to be kept from the
+ *     compiler -- a value with a load in flight must never be copied -- and amdgpu_num_vgpr does
+ *     not do that: once the kernel grew, the record-mode instantiation used four of them for
+ *     values of its own, the text was garbage and a gather went out of bounds.  The wait it
+ *     saved was 130 to 220 of 7,300 cycles;
+ *   - complete items written by the lane that owns the position, in straight-line code over its
+ *     16 positions (no staged text, no rebuild, one LDS round trip per batch instead of two and
+ *     no loop over the set bits): 16 exec-mask changes and 32 more vector instructions per group;
+ *     count only 1.60 -> 1.79 ms, records 2.04 -> 2.09. */
 constexpr uint32_t G2_STAGE = WAVE * 16 + 16; /* a group of text + the 8 bytes behind it (padded) */
 constexpr uint32_t G2_LIST = 128;             /* survivor positions listed per round, 2 bytes each */
 constexpr uint32_t G2_Q2 = 64;                /* walk queue, 8-byte items */
@@ -48,9 +76,8 @@ wave_incl_scan_dpp (uint32_t v) {
   return v;
 }
 
-constexpr int G2_COMPILER_VGPRS = 104; /* v[104:127]: the four sets of text registers (inline assembly only) */
 template <bool COUNT_ONLY, bool TILED>
-__global__ __launch_bounds__ (SPARSE_THREADS) __attribute__ ((amdgpu_num_vgpr (G2_COMPILER_VGPRS))) void
+__global__ __launch_bounds__ (SPARSE_THREADS) void
 scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, uint2 *items, uint32_t region_items,
                    uint32_t *fill, RecHole *holes, uint32_t resume, TileEntry *dir, uint32_t dir_base) {
   (void)items;
@@ -140,44 +167,10 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
   auto lds_word = [&] (uint32_t byte_off) -> uint32_t {
     return *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (byte_off);
   };
-  /* The text of a group in registers: this lane's 16 bytes and the 8 behind them (the next lane's
-   * first; for lane 63 the next group's).  Loaded by inline assembly four groups ahead and waited for
-   * by hand: the compiler cannot count the loads in flight across the pipeline steps' conditional
-   * gathers, so every wait it places on a loop-carried load is s_waitcnt vmcnt(0) -- at the top of
-   * a group that waited for the two gathers the last pipeline step of the group before had JUST
-   * issued, a full L2 / Infinity Cache round trip per group and wave (0.68 of the 2.0 ms a count-only
-   * launch of 2 GiB took).  A set's loads are always followed by those of the three sets behind it
-   * (six operations, vmcnt counts in issue order), so "at most six outstanding" means this set has
-   * landed, whatever else has been issued since -- and leaves the newest gathers in flight.
-   * The four sets live in v[104:127], registers the compiler is told not to allocate
-   * (amdgpu_num_vgpr on the kernel): a value with a load in flight must never be copied, and the
-   * compiler copies values as it likes (with the sets as variables it moved a set to the registers of
-   * an asm operand IN FRONT of the wait).  sieve_group's copies of them are made behind the wait. */
-#define G2_SET_REGS(n) "v" #n
-#define G2_TEXT_ISSUE(M0, M3, T0, T1, c0, c1, c2, c3, c4, c5)                                                              \
-  asm volatile ("global_load_dwordx4 v[" #M0 ":" #M3 "], %0, %2\n\tglobal_load_dwordx2 v[" #T0 ":" #T1 "], %1, %2"           \
-                :: "v"(om), "v"(ot), "s"(text) : "memory", c0, c1, c2, c3, c4, c5)
-#define G2_TEXT_TAKE(M0, M1, M2, M3, T0, T1)                                                                               \
-  asm volatile ("s_waitcnt vmcnt(6)\n\tv_mov_b32 %0, v" #M0 "\n\tv_mov_b32 %1, v" #M1 "\n\tv_mov_b32 %2, v" #M2                \
-                "\n\tv_mov_b32 %3, v" #M3 "\n\tv_mov_b32 %4, v" #T0 "\n\tv_mov_b32 %5, v" #T1                                  \
-                : "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3), "=v"(w4), "=v"(w5) :: "memory")
-  auto issue_text = [&] (const uint32_t set, const uint32_t g) {
+  const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
+  auto load_group = [&] (uint32_t g) -> uint4 {
     const uint32_t blk = g * WAVE + lane;
-    const uint32_t om = (blk < last_blk ? blk : last_blk) * 16u, ot = (blk + 1 < last_blk ? blk + 1 : last_blk) * 16u;
-    switch (set) { /* (a compile-time constant at every call) */
-    case 0: G2_TEXT_ISSUE (104, 107, 108, 109, "v104", "v105", "v106", "v107", "v108", "v109"); break;
-    case 1: G2_TEXT_ISSUE (110, 113, 114, 115, "v110", "v111", "v112", "v113", "v114", "v115"); break;
-    case 2: G2_TEXT_ISSUE (116, 119, 120, 121, "v116", "v117", "v118", "v119", "v120", "v121"); break;
-    default: G2_TEXT_ISSUE (122, 125, 126, 127, "v122", "v123", "v124", "v125", "v126", "v127"); break;
-    }
-  };
-  auto take_text = [&] (const uint32_t set, uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &w3, uint32_t &w4, uint32_t &w5) {
-    switch (set) {
-    case 0: G2_TEXT_TAKE (104, 105, 106, 107, 108, 109); break;
-    case 1: G2_TEXT_TAKE (110, 111, 112, 113, 114, 115); break;
-    case 2: G2_TEXT_TAKE (116, 117, 118, 119, 120, 121); break;
-    default: G2_TEXT_TAKE (122, 123, 124, 125, 126, 127); break;
-    }
+    return text16[blk < last_blk ? blk : last_blk];
   };
   auto walk_batch = [&] (uint32_t n_items) {
     const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, 2> (Ks, Es, text, q2, qn2, n_items, hits, counted);
@@ -186,6 +179,45 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
     if (!COUNT_ONLY)
       rs = rec_state_load (hits); /* (the walk may have gone on to the next chunk) */
   };
+  /* Walk candidates between the entry and the walk queue: a candidate's first look is its depth-5
+   * state's peek entry -- {its record, the symbol of its only edge} -- against the 6th symbol, whose
+   * class came along: 25 of 26 end there.  Left to walk_starts (as scan_gram_kernel does) that look
+   * is a call with a gather and a wait of its own, 1,200 to 2,200 of the 7,300 to 9,100 cycles a wave
+   * spent per group (cycle stamps of a diagnostic build); here the gather is issued when the entry
+   * is looked at and looked at a step later, and only what passes goes to the walk queue, as the
+   * record item walk_starts would have made of it.  (Plans with 4-byte peek entries and relative
+   * state ids: automata of fewer than 2^23 states; others queue the candidates as before.) */
+  uint32_t peek_pos = 0, peek_cls = 0, peek_val = 0, peek_n = 0; /* per lane: position, class of the next symbol | valid << 31, the entry (landing); wave: any in flight */
+  /* (record scans: 2.04 -> 1.98 ms per 2 GiB of config 3; a count-only scan has no records to write in
+   * the walk and measured 4 % SLOWER with the extra stage: it keeps the plain queue) */
+  const bool peek_inline = !COUNT_ONLY && K.peek_packed && K.d5_rel;
+  auto push_walk = [&] (bool go, uint32_t ix, uint32_t iy) {
+    const uint64_t m = __ballot (go);
+    if (m) {
+      /* (a walk call handles one level of the newest items and never leaves more than it took,
+       * and every item ends within lmax levels) */
+      while (qn2 + (uint32_t)__popcll (m) > G2_Q2)
+        walk_batch (qn2 < WAVE ? qn2 : WAVE);
+      if (go)
+        q2[qn2 + rank_below (m)] = make_uint2 (ix, iy);
+      qn2 = uniform (qn2 + (uint32_t)__popcll (m));
+#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 2 /* experiment: the walk candidates are queued and dropped */
+      qn2 = 0;
+#endif
+      while (qn2 >= WAVE)
+        walk_batch (WAVE);
+    }
+  };
+  auto resolve_peeks = [&] () {
+    if (peek_n == 0)
+      return;
+    const uint32_t ev = peek_val, cls = peek_cls & 31u;
+    const uint32_t sym = (ev >> 31) ? GRAM_NO_PEEK : (ev >> 23) & 0xFFu; /* (GramK::g5peek, packed: record | symbol << 23 | "look at the record" << 31) */
+    const uint32_t c1 = cls < K.span ? K.lo + cls : 0x100u;              /* (no symbol of the alphabet, or beyond the text: matches no edge) */
+    const bool on = (peek_cls >> 31) != 0 && (sym == GRAM_NO_PEEK || sym == c1);
+    peek_n = 0;
+    push_walk (on, peek_pos, (ev & 0x7FFFFFu) | WI_RECORD | cls << 24);
+  };
   /* The batch in flight is looked at: a keyword of 4 symbols ends here (reported at once: the
    * entry brought its id along); the 5th symbol is an edge of the depth-4 state (a walk candidate
    * at the depth-5 state it leads to, the class of the 6th symbol riding along: the walk's first
@@ -193,6 +225,7 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
   auto consume_pending = [&] () {
     if (pend_n == 0)
       return;
+    DIAG (const unsigned long long d_c0 = __builtin_readcyclecounter (); asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long d_c1 = __builtin_readcyclecounter (); d_cwait += d_c1 - d_c0; d_steps++; const unsigned long long d_w0 = d_walk;)
     /* (words, not a struct: a uint2 assigned under a condition was put in scratch memory) */
     struct { uint32_t x, y; } e = { pend_e.x, pend_e.y };
     const bool valid = lane < pend_n && (pend_r & PEND_NEED) != 0;
@@ -219,27 +252,25 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
     if (!COUNT_ONLY)
       counted = uniform ((uint32_t)counted);
 #endif
-    const uint32_t c4 = (pend_item.y >> 20) & 31u;
-    const bool pass = ((e.x >> c4) & 1u) != 0 || at_record; /* (classes are below 30: never one of the two flag bits) */
-    const uint64_t m = __ballot (pass);
-    if (m) {
-      /* (a walk call handles one level of the newest items and never leaves more than it took,
-       * and every item ends within lmax levels) */
-      while (qn2 + (uint32_t)__popcll (m) > G2_Q2)
-        walk_batch (qn2 < WAVE ? qn2 : WAVE);
-      if (pass) {
-        const uint32_t st5 = e.y + __popc (e.x & ((1u << c4) - 1u));
-        q2[qn2 + rank_below (m)] = at_record ? make_uint2 (pend_item.x + 3, e.y | WI_RECORD | (K.d5_rel ? c4 << 24 : 0u))
-                                             : make_uint2 (pend_item.x + 4, K.d5_rel ? (st5 - K.d5_begin) | ((pend_item.y >> 25) & 31u) << 24 : st5);
-      }
-      qn2 = uniform (qn2 + (uint32_t)__popcll (m));
-#if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 2 /* experiment: the walk candidates are queued and dropped */
-      qn2 = 0;
-#endif
-      while (qn2 >= WAVE)
-        walk_batch (WAVE);
-    }
+    const uint32_t c4 = (pend_item.y >> 20) & 31u, c5 = (pend_item.y >> 25) & 31u;
+    const bool child = ((e.x >> c4) & 1u) != 0 && !at_record; /* (classes are below 30: never one of the flag bits) */
+    const uint32_t st5 = e.y + __popc (e.x & ((1u << c4) - 1u));
+    if (peek_inline) {
+      /* the 5th symbol leads to depth-5 state st5: its peek entry is asked for, to be looked at a step later */
+      resolve_peeks ();
+      uint32_t pv = 0;
+      if (child)
+        pv = K.g5peek[st5 - K.d5_begin];
+      peek_val = pv;
+      peek_pos = pend_item.x + 4;
+      peek_cls = c5 | (child ? 0x80000000u : 0u);
+      peek_n = __ballot (child) != 0 ? 1u : 0u;
+      push_walk (at_record, pend_item.x + 3, e.y | WI_RECORD | c4 << 24);
+    } else
+      push_walk (child || at_record, at_record ? pend_item.x + 3 : pend_item.x + 4,
+                 at_record ? e.y | WI_RECORD | (K.d5_rel ? c4 << 24 : 0u) : (K.d5_rel ? (st5 - K.d5_begin) | c5 << 24 : st5));
     pend_n = 0;
+    DIAG (d_cons += (__builtin_readcyclecounter () - d_c1) - (d_walk - d_w0);)
   };
   /* One step: the batch in flight is looked at, the n items in lanes [0, n) of (it_x, it_y) send
    * for their entries -- the word of the table says which slot of the word's line is theirs. */
@@ -268,11 +299,15 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
   /* one group, first half: the sieve.  S holds the group's text (waited for here) and is asked for
    * the group four ahead as soon as its bytes have become classes; leaves the lane's survivors as
    * the even bits of `pass`, the number of its first one among the group's in `my`, returns their total */
-  auto sieve_group = [&] (const uint32_t set, const uint32_t g, uint32_t &pass_out, uint32_t &my_out) -> uint32_t {
+  auto sieve_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t next_y, const uint32_t g, uint4 &prefetched, uint32_t &pass_out, uint32_t &my_out) -> uint32_t {
     typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
     typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
-    uint32_t t0, t1, t2, t3, t4, t5;
-    take_text (set, t0, t1, t2, t3, t4, t5);
+    uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp ((int)uniform (next_x), (int)cur.x, 0x130, 0xf, 0xf, false);
+    const uint32_t t5 = (uint32_t)__builtin_amdgcn_update_dpp ((int)uniform (next_y), (int)cur.y, 0x130, 0xf, 0xf, false);
+    asm volatile ("" : "+v"(t4));
+    __builtin_amdgcn_sched_barrier (0);
+    prefetched = load_group (g + 4);
+    const uint32_t t0 = cur.x, t1 = cur.y, t2 = cur.z, t3 = cur.w;
     /* the group's text where the lanes that take its survivors off the list find it */
     *reinterpret_cast<__attribute__ ((address_space (3))) u32x4 *> (stage_off + lane * 16u) = u32x4{ t0, t1, t2, t3 };
     if (lane == WAVE - 1)
@@ -281,7 +316,6 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
     const uint32_t w[5] = { t0, t1, t2, t3, t4 };
 #if defined(ACM_GRAM2_ABLATE) && ACM_GRAM2_ABLATE == 7 /* experiment: the text is streamed and staged, not looked at */
     asm volatile ("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
-    issue_text (set, g + 4);
     pass_out = 0;
     return 0;
 #endif
@@ -299,7 +333,6 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
           c[j] = K.span;
     }
     /* (the set has been copied out: its registers take the group four ahead) */
-    issue_text (set, g + 4);
     uint32_t pair[19];
 #pragma unroll
     for (int j = 0; j < 19; j++)
@@ -411,6 +444,7 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
       pk = 0;
     }
     consume_pending ();
+    resolve_peeks ();
     while (qn2)
       walk_batch (qn2 < WAVE ? qn2 : WAVE);
   };
@@ -445,22 +479,19 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
       W->s_begin = W->s_late = stream_index (*W);
     }
     const uint32_t g0 = tile * K.R;
-    issue_text (0, g0);
-    issue_text (1, g0 + 1);
-    issue_text (2, g0 + 2);
-    issue_text (3, g0 + 3);
-    for (uint32_t k = 0; k < K.R; k++) { /* (K.R is a multiple of 4: a tile begins with set 0) */
-      if (tiled && k + 1 == K.R && lane == 0) /* (keywords are no longer than a group here: what ends beyond the tile starts in its last group) */
+    uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
+    for (uint32_t k = 0; k < K.R; k++) {
+      if (tiled && k + 1 == K.R && lane == 0)
         Ws[wib].s_late = stream_index (Ws[wib]);
-      uint32_t pass = 0, my = 0, total;
-      switch (k & 3u) { /* (four copies of the sieve, one per set of registers; the rest of the group once) */
-      case 0: total = sieve_group (0, g0 + k, pass, my); break;
-      case 1: total = sieve_group (1, g0 + k, pass, my); break;
-      case 2: total = sieve_group (2, g0 + k, pass, my); break;
-      default: total = sieve_group (3, g0 + k, pass, my); break;
-      }
+      uint4 n3;
+      uint32_t pass = 0, my = 0;
+      const uint32_t total = sieve_group (c0, c1.x, c1.y, g0 + k, n3, pass, my);
       if (total)
         take_group (g0 + k, total, pass, my);
+      c0 = c1;
+      c1 = c2;
+      c2 = c3;
+      c3 = n3;
     }
   }
   if (!tiled)

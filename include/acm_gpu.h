@@ -13,10 +13,12 @@
  * machine->nb_sequences had just before aho_corasick.c:352), in the loop's order
  * (end_pos ascending, then j ascending == length descending).
  *
- * All of it runs on the GPU as hand-written HIP; there is NO CPU fallback: a machine the GPU
- * path cannot take (symbol size not in {1,2,4,8}; a comparator other than ACM_CMP_DEFAULT unless
+ * The acm_gpu_* functions run on the GPU as hand-written HIP and have NO CPU fallback: a machine
+ * they cannot take (symbol size not in {1,2,4,8}; a comparator other than ACM_CMP_DEFAULT unless
  * the plan is made with acm_gpu_plan_create_classes) or a missing device is reported as an error
- * code and the caller keeps using the per-symbol API.
+ * code.  acm_scan, the call on the machine itself, is total over machines: what the
+ * GPU cannot take by its nature runs the loop above on the host and says so (acm_scan_path); a
+ * missing device is still an error there, never a silent fallback.
  *
  * Plain C ABI: pointers and sizes only.  `stream` arguments are a hipStream_t passed as void *
  * (NULL = the default stream); `d_` pointers are device memory on the plan's device.
@@ -260,10 +262,30 @@ int acm_gpu_scan_ordered_device (ACMPlan *plan, const void *d_text, uint64_t n_s
 int acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint64_t emit_from,
                        uint64_t pos_base, ACMRecord *records, uint64_t capacity, uint64_t *n_found);
 
-/* The bulk call on the machine itself: keeps a plan cached inside the machine and rebuilds it
- * when the dictionary changed since the last call.  Device = $ACM_GPU_DEVICE or 0. */
+/* The bulk call on the machine itself, for EVERY machine the reference's API can make
+ * (aho_corasick.h:33-45: any comparator, any symbol): the records of the caller's loop over
+ * text[0 .. n_symbols), in the loop's order.  Keeps a plan cached inside the machine and brings it
+ * up to date when the dictionary changed since the last call.  Device = $ACM_GPU_DEVICE or 0.
+ *   - ACM_CMP_DEFAULT over 1, 2, 4 or 8 byte symbols: the GPU scan (ACM_SCAN_PATH_GPU);
+ *   - another comparator: the library cannot know the symbol size (letters are opaque pointers), so
+ *     the caller says it once with acm_set_symbol_bytes.  1, 2 or 4 bytes: the GPU scan over the
+ *     comparator's symbol classes (acm_gpu_plan_create_classes; ACM_SCAN_PATH_GPU_CLASSES) -- the
+ *     reference's own example, wchar_t + alphacmp (examples/aho_corasick_generic_test.c:48-54), runs
+ *     this way.  Any other size, or a comparator that is no consistent order over all symbol values
+ *     (acm_flatten_classes refuses it): the loop itself, on the host, with this library's own
+ *     acm_match / acm_get_match steps (ACM_SCAN_PATH_CPU_LOOP) -- SURVEY.md 8(b): "otherwise it runs
+ *     loop a9 on the CPU".  Without acm_set_symbol_bytes such a machine is ACM_GPU_E_INELIGIBLE.
+ * A missing device or a failing HIP call is an ERROR for the machines of the first two kinds
+ * (ACM_GPU_E_NODEVICE, ACM_GPU_E_HIP): the GPU path never falls back to the host silently.
+ * acm_scan_path says which of the three the machine's last acm_scan ran. */
+#define ACM_SCAN_PATH_NONE 0
+#define ACM_SCAN_PATH_GPU 1
+#define ACM_SCAN_PATH_GPU_CLASSES 2
+#define ACM_SCAN_PATH_CPU_LOOP 3
 int acm_scan (ACMachine *machine, const void *text, uint64_t n_symbols, ACMRecord *records,
               uint64_t capacity, uint64_t *n_found);
+int acm_set_symbol_bytes (ACMachine *machine, uint32_t sym_bytes);
+int acm_scan_path (const ACMachine *machine);
 
 /* ------------------------------------------------------------------ streaming scan
  * Text that arrives piece by piece from the host (the reference's callers read files symbol by
