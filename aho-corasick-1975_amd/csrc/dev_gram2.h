@@ -170,7 +170,11 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
   const uint4 *text16 = reinterpret_cast<const uint4 *> (text);
   auto load_group = [&] (uint32_t g) -> uint4 {
     const uint32_t blk = g * WAVE + lane;
-    return text16[blk < last_blk ? blk : last_blk];
+    /* (non-temporal: the text is read once -- same time, and the rows' lines stay in L2 more often:
+     * FETCH_SIZE per launch 2.22 -> 1.84 M KB, TCC_MISS 42 -> 36 M) */
+    typedef uint32_t nt_u32x4 __attribute__ ((ext_vector_type (4)));
+    const nt_u32x4 v = __builtin_nontemporal_load (reinterpret_cast<const nt_u32x4 *> (text16) + (blk < last_blk ? blk : last_blk));
+    return make_uint4 (v.x, v.y, v.z, v.w);
   };
   auto walk_batch = [&] (uint32_t n_items) {
     const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, 2> (Ks, Es, text, q2, qn2, n_items, hits, counted);

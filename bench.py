@@ -263,6 +263,8 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
         algo_bytes = (float(n_own) * sym + rec_bytes_scan * n_matches) / launches_per_step
         achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
         kname = KERNELS.get(info["kernel"], "kernel %d" % info["kernel"])
+        if info["kernel"] == 5 and info.get("variant") == 2:
+            kname = "scan_gram2_kernel"     # the 4-gram kernel with the lane-local sieve (dev_gram2.h)
         # HBM bytes per launch of the scan kernel come from separate rocprofv3 --pmc passes of this
         # command (tools/collect_profiles.sh -> profiles/traffic_config<c>.json): counters cannot
         # be read in-process, so this is NOT from the run that prints this line and says so
@@ -419,7 +421,20 @@ def cpu_baseline(acm, machine, kd, ko, dev_sample, sym, gpu_on_sample):
         sample = sample.view(np.uint32)
     n = sample.size
     nbytes = n * sym
-    cores = len(os.sched_getaffinity(0))
+    cores = len(os.sched_getaffinity(0))      # hardware threads this process may run on
+    cpu_model, phys = "unknown", set()
+    try:
+        with open("/proc/cpuinfo") as f:
+            pid = None
+            for line in f:
+                if line.startswith("model name") and cpu_model == "unknown":
+                    cpu_model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    pid = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    phys.add((pid, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
     o = po.Oracle(sym, po.MEYER85)
     o.add_keywords_packed(kd, ko)
     t0 = time.perf_counter()
@@ -432,6 +447,8 @@ def cpu_baseline(acm, machine, kd, ko, dev_sample, sym, gpu_on_sample):
     assert ok, "GPU records differ from the CPU oracle on the sample prefix: %r %r %r" % ((cnt1, dig1), (cntT, digT), gpu_on_sample)
     res = {
         "value": round(nbytes / tT / 1e9, 5), "unit": "GB/s", "cores": cores, "kind": "port",
+        "cores_are": "hardware threads (os.sched_getaffinity), one scanning thread each", "cpu_model": cpu_model,
+        "physical_cores": len(phys) or None,
         "sample": "first %d MiB of the rank-0 text; oracle/ac_oracle.c (restatement of aho_corasick.c), "
                   "%d threads sharded with lmax-1 overlap; GPU records on the sample verified equal (count + digest)" % (
                       nbytes >> 20, cores),

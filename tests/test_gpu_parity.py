@@ -529,6 +529,46 @@ def test_dense_region_overflow_many_times_per_wave(torch_cuda, monkeypatch):
     assert acm.synth.device_digest(rec, int(cnt.item())) == (want_n, want_d)
 
 
+@pytest.mark.parametrize("kind", ["dense", "gram2", "gram", "starts"])
+def test_small_grids_every_part_of_the_tile_pool_has_a_block(torch_cuda, monkeypatch, kind):
+    """Grids of fewer blocks than the tile pool has parts (a partitioned device, ACM_GPU_GRID_BLOCKS):
+    the last sixteenth of a launch's tiles is a pool in up to 16 parts, and block b draws from part
+    b * parts / blocks -- with 16 parts and fewer than 16 blocks some parts had no block at all and
+    their tiles were never scanned (a work-in-progress build of round 3 lost exactly 15/256 of the
+    records on a one-block grid; fixed by parts = min (16, blocks)).  Grids of 1, 3, 15, 17 and 20
+    blocks, texts long enough for a pool, every kernel family that has one, against the oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(616)
+    if kind == "dense":
+        kws = [bytes(rng.integers(97, 123, size=int(rng.integers(3, 9)), dtype=np.uint8)) for _ in range(300)] + [b"ab", b"q"]
+        sym, text, env, kernel = 1, rng.integers(97, 123, size=(24 << 20) + 5, dtype=np.uint8), {}, 1
+    elif kind in ("gram2", "gram"):
+        kws = [rng.integers(97, 104, size=rng.integers(4, 13)).astype(np.uint8) for _ in range(3000)]
+        sym, text, kernel = 1, rng.integers(96, 105, size=(12 << 20) + 77).astype(np.uint8), 5
+        env = {"ACM_GPU_GRAM": "2"} if kind == "gram2" else {"ACM_GPU_GRAM": "2", "ACM_GPU_GRAM2": "0"}
+    else:
+        kws = [rng.integers(0, 3000, size=rng.integers(1, 6)).astype(np.uint32) for _ in range(2000)]
+        sym, text, env, kernel = 4, rng.integers(0, 3003, size=(6 << 20) + 3).astype(np.uint32), {}, 4
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _, o = build_pair(kws, sym)
+    want_n, want_d = o.scan_mt(text, 8)
+    assert want_n > 10000
+    dev = _dev(torch, text)
+    for blocks in (1, 3, 15, 17, 20):
+        monkeypatch.setenv("ACM_GPU_GRID_BLOCKS", str(blocks))
+        m, _ = build_pair(kws, sym)
+        plan = m.plan(0)
+        assert plan.info.kernel == kernel and plan.info.grid_blocks in (blocks, blocks * 16), (kind, plan.describe())
+        if kind.startswith("gram"):
+            assert plan.info.variant == (2 if kind == "gram2" else 0)
+        rec, cnt = plan.scan(dev, capacity=want_n + 16)
+        assert acm.synth.device_digest(rec, int(cnt.item())) == (want_n, want_d), (kind, blocks)
+        assert int(plan.count(dev).item()) == want_n, (kind, blocks)
+        plan.status()
+        del rec, cnt, plan, m
+
+
 @pytest.mark.parametrize("mode", ["sticky", "gram"])
 def test_rows_colder_than_lds(torch_cuda, monkeypatch, mode):
     """A dictionary whose rows do not all fit in LDS: transitions through HBM-resident rows (sticky

@@ -15,6 +15,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $set | tr " " "_" | cut -c1-32)
   rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$name -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-other-configs > /dev/null 2> $OUT/pmc_$name.err || echo "pmc $name failed"
+  echo "pass $name done" >> $OUT/progress.txt
 done
 python3 - <<PY
 import csv, glob, collections, json, re
@@ -25,11 +26,13 @@ pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/pmc_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        k = next((x for x in ("scan_dense_kernel", "scan_gram_kernel", "scan_starts_kernel", "expand_items", "expand_hits", "close_holes", "tile_gather", "tile_size", "order_bucket", "order_finish") if x in n), None)
+        k = next((x for x in ("scan_dense_kernel", "scan_gram2_kernel", "scan_gram_kernel", "scan_starts_kernel", "expand_items", "expand_hits", "close_holes", "tile_gather", "tile_size", "order_bucket", "order_finish") if x in n), None)
         if k == "scan_gram_kernel" and re.search(r"scan_gram_kernel<[^>]*, true>", n):
             k = "scan_gram_kernel_tiled"   # (the e2e leg's scan: acm_gpu_scan_ordered_device)
         # record-mode instantiations only (the count-only pass that sizes the record buffer is another kernel)
-        count_only = ("scan_gram_kernel<true" in n or
+        if k == "scan_gram2_kernel" and re.search(r"scan_gram2_kernel<[^>]*, true>", n):
+            k = "scan_gram2_kernel_tiled"
+        count_only = ("scan_gram_kernel<true" in n or "scan_gram2_kernel<true" in n or
                       (("scan_dense_kernel" in n or "scan_starts_kernel" in n) and ", true>(" in n))
         if k and not count_only:
             pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
