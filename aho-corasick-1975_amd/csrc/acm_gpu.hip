@@ -2877,6 +2877,19 @@ struct ACMMulti {
   std::vector<ACMPlan *> plan; /* per distinct device */
   std::vector<hipStream_t> stream;
   uint32_t lmax = 0, sym_bytes = 1;
+  /* what a shard's scan needs on its device, kept from call to call (grow-only): hipMalloc and
+   * hipFree wait for the device, and a scan of config 4 wants 7 GB of records + twice that of
+   * scratch per shard -- allocated once, sized by what the call before found */
+  struct ShardBuf {
+    ACMRecord *rec = nullptr;
+    uint64_t rec_cap = 0;
+    uint64_t *cnt = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_cap = 0;
+    uint64_t last_found = 0, last_span = 0;
+  };
+  std::vector<ShardBuf> buf; /* per shard */
+  uint64_t *h_found = nullptr; /* pinned, one count per shard */
   int slot_of (int device) const {
     for (size_t i = 0; i < distinct.size (); i++)
       if (distinct[i] == device)
@@ -2898,6 +2911,14 @@ acm_gpu_multi_destroy (ACMMulti *mu) {
     if (i < mu->plan.size () && mu->plan[i])
       acm_gpu_plan_destroy (mu->plan[i]);
   }
+  for (size_t r = 0; r < mu->buf.size (); r++) {
+    (void)hipSetDevice (mu->dev[r]);
+    if (mu->buf[r].rec) (void)hipFree (mu->buf[r].rec);
+    if (mu->buf[r].cnt) (void)hipFree (mu->buf[r].cnt);
+    if (mu->buf[r].tmp) (void)hipFree (mu->buf[r].tmp);
+  }
+  if (mu->h_found)
+    (void)hipHostFree (mu->h_found);
   delete mu;
 }
 
@@ -2933,6 +2954,13 @@ acm_gpu_multi_create (ACMachine *machine, const int *devices, int n_shards, ACMM
   mu->sym_bytes = fi.sym_bytes;
   mu->plan.assign (mu->distinct.size (), nullptr);
   mu->stream.assign (mu->distinct.size (), nullptr);
+  mu->buf.assign (mu->dev.size (), ACMMulti::ShardBuf ());
+  if (hipHostMalloc (reinterpret_cast<void **> (&mu->h_found), mu->dev.size () * sizeof (uint64_t), hipHostMallocDefault) != hipSuccess) {
+    mu->h_found = nullptr;
+    acm_flat_release (flat);
+    delete mu;
+    return ACM_GPU_E_NOMEM;
+  }
   for (size_t i = 0; i < mu->distinct.size () && !rc; i++) {
     rc = acm_gpu_plan_create_flat (flat, mu->distinct[i], &mu->plan[i]);
     if (!rc && (hipSetDevice (mu->distinct[i]) != hipSuccess || hipStreamCreateWithFlags (&mu->stream[i], hipStreamNonBlocking) != hipSuccess))
@@ -2983,78 +3011,95 @@ int
 multi_scan (ACMMulti *mu, const void *const *d_text, uint64_t n, ACMRecord *d_out, uint64_t capacity, uint64_t *n_found) {
   const size_t R = mu->dev.size ();
   struct Shard {
-    ACMRecord *rec = nullptr;
-    uint64_t *cnt = nullptr;
-    void *tmp = nullptr;
-    uint64_t cap = 0, found = 0, rb = 0, b = 0, e = 0;
+    uint64_t rb = 0, b = 0, e = 0;
     int slot = 0;
-    hipEvent_t done = nullptr;
   };
   std::vector<Shard> sh (R);
   int rc = ACM_GPU_OK;
-  auto cleanup = [&] () {
-    for (auto &s : sh) {
-      (void)hipSetDevice (mu->distinct[s.slot]);
-      (void)hipStreamSynchronize (mu->stream[s.slot]);
-      if (s.rec) (void)hipFree (s.rec);
-      if (s.cnt) (void)hipFree (s.cnt);
-      if (s.tmp) (void)hipFree (s.tmp);
-      if (s.done) (void)hipEventDestroy (s.done);
-    }
-  };
 #define MULTI_TRY(expr)                                                                            \
   do {                                                                                             \
     hipError_t _e = (expr);                                                                        \
     if (_e != hipSuccess) {                                                                        \
       fprintf (stderr, "acm_gpu: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString (_e), __FILE__, __LINE__); \
-      cleanup ();                                                                                  \
+      for (size_t i_ = 0; i_ < mu->distinct.size (); i_++) {                                       \
+        (void)hipSetDevice (mu->distinct[i_]);                                                     \
+        (void)hipStreamSynchronize (mu->stream[i_]);                                               \
+      }                                                                                            \
       return _e == hipErrorOutOfMemory ? ACM_GPU_E_NOMEM : ACM_GPU_E_HIP;                          \
     }                                                                                              \
   } while (0)
-  /* first pass: every shard with a record buffer sized by a guess (one match per 32 symbols); the
-   * count tells which shards need a second pass with the exact size */
-  for (size_t r = 0; r < R; r++) {
-    Shard &s = sh[r];
-    s.slot = mu->slot_of (mu->dev[r]);
-    (void)acm_gpu_multi_shard_bounds (mu, n, (int)r, &s.rb, &s.b, &s.e);
-    MULTI_TRY (hipSetDevice (mu->dev[r]));
-    MULTI_TRY (hipEventCreateWithFlags (&s.done, hipEventDisableTiming));
-    MULTI_TRY (hipMalloc (reinterpret_cast<void **> (&s.cnt), 8));
-    s.cap = (s.e - s.b) / 32 + 4096;
-    MULTI_TRY (hipMalloc (reinterpret_cast<void **> (&s.rec), s.cap * sizeof (ACMRecord)));
-  }
+  /* a shard's record buffer and scratch: at least `want` records (grow-only, kept by the handle) */
+  auto ensure = [&] (size_t r, uint64_t want) -> int {
+    ACMMulti::ShardBuf &B = mu->buf[r];
+    const Shard &s = sh[r];
+    if (!B.cnt && hipMalloc (reinterpret_cast<void **> (&B.cnt), 8) != hipSuccess)
+      return ACM_GPU_E_NOMEM;
+    if (B.rec_cap < want) {
+      if (B.rec)
+        (void)hipFree (B.rec);
+      B.rec = nullptr;
+      B.rec_cap = 0;
+      if (hipMalloc (reinterpret_cast<void **> (&B.rec), want * sizeof (ACMRecord)) != hipSuccess)
+        return ACM_GPU_E_NOMEM;
+      B.rec_cap = want;
+    }
+    const size_t tb = s.e > s.b ? acm_gpu_scan_ordered_tmp_bytes (mu->plan[s.slot], B.rec_cap, s.e - s.rb) : 0;
+    if (B.tmp_cap < tb) {
+      if (B.tmp)
+        (void)hipFree (B.tmp);
+      B.tmp = nullptr;
+      B.tmp_cap = 0;
+      if (hipMalloc (&B.tmp, tb) != hipSuccess)
+        return ACM_GPU_E_NOMEM;
+      B.tmp_cap = tb;
+    }
+    return ACM_GPU_OK;
+  };
+  /* first pass: every shard into a record buffer sized by what the call before found on a text of
+   * this length (+ an eighth), or by a guess (one match per 32 symbols); the counts tell which
+   * shards need a second pass with the exact size */
   for (int pass = 0; pass < 2; pass++) {
     bool any = false;
     for (size_t r = 0; r < R; r++) {
       Shard &s = sh[r];
-      if (pass == 1 && s.found <= s.cap)
+      ACMMulti::ShardBuf &B = mu->buf[r];
+      if (pass == 0) {
+        s.slot = mu->slot_of (mu->dev[r]);
+        (void)acm_gpu_multi_shard_bounds (mu, n, (int)r, &s.rb, &s.b, &s.e);
+      } else if (mu->h_found[r] <= B.rec_cap)
         continue; /* the first pass had room for everything it found */
       any = true;
       MULTI_TRY (hipSetDevice (mu->dev[r]));
-      if (pass == 1) {
-        MULTI_TRY (hipFree (s.rec));
-        s.rec = nullptr;
-        s.cap = s.found;
-        MULTI_TRY (hipMalloc (reinterpret_cast<void **> (&s.rec), s.cap * sizeof (ACMRecord)));
+      uint64_t want = mu->h_found[r];
+      if (pass == 0) {
+        const uint64_t span = s.e - s.b;
+        want = B.last_found && B.last_span == span ? B.last_found + B.last_found / 8 + 4096 : span / 32 + 4096;
+        if (want < B.rec_cap)
+          want = B.rec_cap;
+      }
+      rc = ensure (r, want);
+      if (rc) {
+        for (size_t i = 0; i < mu->distinct.size (); i++) {
+          (void)hipSetDevice (mu->distinct[i]);
+          (void)hipStreamSynchronize (mu->stream[i]);
+        }
+        return rc;
       }
       /* (shards of one device share its stream: their scans run one after the other.)  Scan and
        * canonical order in one call: nothing waits for the host between them, and 4-gram plans scan
        * in tiles and order in one pass */
       if (s.e > s.b) {
-        if (s.tmp) {
-          MULTI_TRY (hipFree (s.tmp));
-          s.tmp = nullptr;
-        }
-        const size_t tb = acm_gpu_scan_ordered_tmp_bytes (mu->plan[s.slot], s.cap, s.e - s.rb);
-        MULTI_TRY (hipMalloc (&s.tmp, tb));
-        rc = acm_gpu_scan_ordered_device (mu->plan[s.slot], d_text[r], s.e - s.rb, s.b - s.rb, s.rb, s.rec, s.cap, s.cnt, s.tmp, tb, mu->stream[s.slot]);
+        rc = acm_gpu_scan_ordered_device (mu->plan[s.slot], d_text[r], s.e - s.rb, s.b - s.rb, s.rb, B.rec, B.rec_cap, B.cnt, B.tmp, B.tmp_cap, mu->stream[s.slot]);
         if (rc) {
-          cleanup ();
+          for (size_t i = 0; i < mu->distinct.size (); i++) {
+            (void)hipSetDevice (mu->distinct[i]);
+            (void)hipStreamSynchronize (mu->stream[i]);
+          }
           return rc;
         }
       } else
-        MULTI_TRY (hipMemsetAsync (s.cnt, 0, 8, mu->stream[s.slot]));
-      MULTI_TRY (hipMemcpyAsync (&s.found, s.cnt, 8, hipMemcpyDeviceToHost, mu->stream[s.slot]));
+        MULTI_TRY (hipMemsetAsync (B.cnt, 0, 8, mu->stream[s.slot]));
+      MULTI_TRY (hipMemcpyAsync (&mu->h_found[r], B.cnt, 8, hipMemcpyDeviceToHost, mu->stream[s.slot]));
     }
     if (!any)
       break;
@@ -3064,26 +3109,28 @@ multi_scan (ACMMulti *mu, const void *const *d_text, uint64_t n, ACMRecord *d_ou
     }
   }
   uint64_t total = 0;
-  for (auto &s : sh)
-    total += s.found;
-  *n_found = total;
-  if (total > capacity) {
-    cleanup ();
-    return ACM_GPU_E_OVERFLOW;
+  for (size_t r = 0; r < R; r++) {
+    total += mu->h_found[r];
+    mu->buf[r].last_found = mu->h_found[r];
+    mu->buf[r].last_span = sh[r].e - sh[r].b;
   }
+  *n_found = total;
+  if (total > capacity)
+    return ACM_GPU_E_OVERFLOW;
   /* (every shard's records are in canonical order where they are:) each shard's run into its place on devices[0] */
   uint64_t off = 0;
   for (size_t r = 0; r < R; r++) {
-    Shard &s = sh[r];
+    const Shard &s = sh[r];
+    const uint64_t found = mu->h_found[r];
     MULTI_TRY (hipSetDevice (mu->dev[r]));
     hipStream_t st = mu->stream[s.slot];
-    if (s.found) {
+    if (found) {
       if (mu->dev[r] == mu->dev[0])
-        MULTI_TRY (hipMemcpyAsync (d_out + off, s.rec, s.found * sizeof (ACMRecord), hipMemcpyDeviceToDevice, st));
+        MULTI_TRY (hipMemcpyAsync (d_out + off, mu->buf[r].rec, found * sizeof (ACMRecord), hipMemcpyDeviceToDevice, st));
       else
-        MULTI_TRY (hipMemcpyPeerAsync (d_out + off, mu->dev[0], s.rec, mu->dev[r], s.found * sizeof (ACMRecord), st));
+        MULTI_TRY (hipMemcpyPeerAsync (d_out + off, mu->dev[0], mu->buf[r].rec, mu->dev[r], found * sizeof (ACMRecord), st));
     }
-    off += s.found;
+    off += found;
   }
   for (size_t i = 0; i < mu->distinct.size (); i++) {
     MULTI_TRY (hipSetDevice (mu->distinct[i]));
@@ -3091,7 +3138,6 @@ multi_scan (ACMMulti *mu, const void *const *d_text, uint64_t n, ACMRecord *d_ou
   }
   for (size_t i = 0; i < mu->distinct.size () && !rc; i++)
     rc = acm_gpu_plan_status (mu->plan[i]);
-  cleanup ();
   return rc;
 #undef MULTI_TRY
 }

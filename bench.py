@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="default line only: leave out the short runs of configs 3 and 5")
     ap.add_argument("--cpu-sample-mib", type=int, default=None)
+    ap.add_argument("--no-multi-c-abi", action="store_true", help="leave out the e2e leg through acm_gpu_multi_scan_device (C ABI)")
     return ap.parse_args()
 
 
@@ -238,6 +239,22 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
             "ms_per_step": round(e2e_elapsed / e2e_steps * 1e3, 4), "steps": e2e_steps,
         }
 
+    # ---- the same end-to-end job through the C ABI's multi-device entry (acm_gpu_multi_scan_device:
+    # one process, shard r on device r, ordered records gathered on device 0 by peer copies) -- what a
+    # C caller of libac75_amd.so runs.  Rank 0 drives it over all N devices while the other ranks
+    # wait at the barrier below; at N = 1 also with 8 shards on the one device.
+    c_abi = None
+    if want_e2e and ctx.get("multi_c_abi", True) and not rehearsal:
+        if rank == 0:
+            try:
+                c_abi = c_abi_leg(ctx, m, kd, ko, sym, n_own, world, text, total_matches, records if world == 1 else None,
+                                  n_matches, 1 if n_matches >= (1 << 24) else 3)
+            except Exception as ex:       # the headline line must not depend on this leg
+                c_abi = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        barrier()
+        if e2e_obj is not None and c_abi is not None:
+            e2e_obj["c_abi"] = c_abi
+
     res = None
     if rank == 0:
         if gathered is not None:
@@ -318,6 +335,57 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
     return res, keep
 
 
+def c_abi_leg(ctx, machine, kd, ko, sym, n_own, world, text0, total_matches, scan_records, n_scan_records, steps):
+    """acm_gpu_multi_scan_device over devices 0 .. world - 1 (and, on one GPU, 8 shards on device 0):
+    shard r's text is generated on device r as the torch ranks generate theirs; the records arrive on
+    device 0 in canonical order and are checked (count, order; on one GPU also the digest of the
+    scan's record set).  Returns the timing object for the bench line."""
+    acm, torch = ctx["acm"], ctx["torch"]
+    n = n_own * world
+    out = {}
+    for label, devices in ((("devices_0_to_%d" % (world - 1)), list(range(world))),) + (((("eight_shards_on_device_0"), [0] * 8),) if world == 1 else ()):
+        mu = acm.binding.MultiScan(machine, devices)
+        shards = []
+        for r, d in enumerate(devices):
+            rb, b, e = mu.shard_bounds(n, r)
+            if d == 0 and world == 1:
+                shards.append(text0[rb:e])                 # (one GPU: the text is already there)
+            elif r == 0:
+                shards.append(text0[:e])
+            else:
+                gen_begin = rb // 4096 * 4096
+                with torch.cuda.device(d):
+                    g = acm.synth.device_text(e - gen_begin, kd, ko, begin=gen_begin, sym_bytes=sym, vocab=VOCAB, device="cuda:%d" % d)
+                shards.append(g[rb - gen_begin:])
+        for t in shards:
+            assert t.data_ptr() % 16 == 0
+        rec = torch.empty((total_matches + 16, 2), dtype=torch.int64, device="cuda:0")
+        found = mu.scan_device(shards, n, rec)            # first call: allocates the shards' buffers
+        assert found == total_matches, (found, total_matches)
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            found = mu.scan_device(shards, n, rec)
+        dt = (time.perf_counter() - t0) / steps
+        assert found == total_matches
+        if found > 1:
+            ln = rec[:found, 1] & 0xFFFFFFFF
+            ok = (rec[1:found, 0] > rec[:found - 1, 0]) | ((rec[1:found, 0] == rec[:found - 1, 0]) & (ln[1:] < ln[:-1]))
+            assert bool(ok.all().item()), "C ABI multi-device scan: records not in canonical order"
+            del ln, ok
+        if scan_records is not None:
+            assert acm.synth.device_digest(rec, found) == acm.synth.device_digest(scan_records, n_scan_records), "C ABI multi-device scan: another record set"
+        out[label] = {"ms_per_step": round(dt * 1e3, 4), "value": round(n * sym / dt / 1e9, 3), "unit": "GB/s", "steps": steps,
+                      "shards": len(devices)}
+        del rec, shards
+        mu.close()
+        torch.cuda.empty_cache()
+    out["what"] = ("acm_gpu_multi_scan_device (C ABI, one process): every shard scanned + ordered on its device, records gathered on "
+                   "device 0 by peer copies; host waits inside the call included")
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -353,7 +421,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    ctx = dict(acm=acm, torch=torch, dist=dist, rank=rank, world=world, dev=dev, rehearsal=rehearsal)
+    ctx = dict(acm=acm, torch=torch, dist=dist, rank=rank, world=world, dev=dev, rehearsal=rehearsal, multi_c_abi=not args.no_multi_c_abi)
 
     res, keep = measure(ctx, args.config, cfg, args.steps, args.warmup, args.prewarm_ms, as_configured)
     out = None
