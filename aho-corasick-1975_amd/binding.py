@@ -80,7 +80,8 @@ EXPORTS = [
     "acm_gpu_plan_timing_read", "acm_gpu_plan_timing_read_all", "acm_gpu_plan_status", "acm_gpu_synth_text",
     "acm_gpu_stream_open", "acm_gpu_stream_feed", "acm_gpu_stream_finish", "acm_gpu_stream_close",
     "acm_gpu_multi_create", "acm_gpu_multi_destroy", "acm_gpu_multi_shard_bounds", "acm_gpu_multi_scan_host",
-    "acm_gpu_multi_scan_device", "acm_set_symbol_bytes", "acm_scan_path",
+    "acm_gpu_multi_scan_device", "acm_set_symbol_bytes", "acm_scan_path", "acm_gpu_wire_bits", "acm_gpu_pack_records_device",
+    "acm_gpu_unpack_records_device",
 ]
 
 
@@ -180,6 +181,12 @@ def lib():
     L.acm_gpu_scan_host.argtypes = [vp, vp, u64, u64, u64, vp, u64, C.POINTER(u64)]
     L.acm_scan.restype = i32
     L.acm_scan.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    L.acm_gpu_wire_bits.restype = i32
+    L.acm_gpu_wire_bits.argtypes = [vp, u64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.acm_gpu_pack_records_device.restype = i32
+    L.acm_gpu_pack_records_device.argtypes = [vp, u64, u64, C.c_uint32, C.c_uint32, vp, vp]
+    L.acm_gpu_unpack_records_device.restype = i32
+    L.acm_gpu_unpack_records_device.argtypes = [vp, u64, u64, C.c_uint32, C.c_uint32, vp, vp]
     L.acm_set_symbol_bytes.restype = i32
     L.acm_set_symbol_bytes.argtypes = [vp, C.c_uint32]
     L.acm_scan_path.restype = i32
@@ -616,6 +623,14 @@ class Plan:
     def stream(self, max_piece_symbols, record_capacity):
         return Stream(self, max_piece_symbols, record_capacity)
 
+    def wire(self, span, pos_lo):
+        """(pos_lo, pos_bits, len_bits) for the 8-byte wire form of the records of a scan of `span` symbols
+        with pos_base = pos_lo (acm_gpu_wire_bits), or None when the fields do not fit 64 bits."""
+        pb, lb, kb = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        if lib().acm_gpu_wire_bits(self.h, int(span), C.byref(pb), C.byref(lb), C.byref(kb)) != 0:
+            return None
+        return int(pos_lo), int(pb.value), int(lb.value)
+
     def status(self):
         """Synchronises and raises if a device-side consistency check failed."""
         _check(lib().acm_gpu_plan_status(self.h), "acm_gpu_plan_status")
@@ -634,6 +649,29 @@ class Plan:
         ms, allms, n = C.c_double(0), C.c_double(0), C.c_uint64(0)
         _check(lib().acm_gpu_plan_timing_read_all(self.h, C.byref(ms), C.byref(allms), C.byref(n)), "acm_gpu_plan_timing_read_all")
         return ms.value, allms.value, int(n.value)
+
+
+def pack_records(records, wire):
+    """acm_gpu_pack_records_device: int64 [n, 2] CUDA tensor of ordered records -> int64 [n] tensor of 8-byte words."""
+    import torch
+    pos_lo, pb, lb = wire
+    n = records.shape[0]
+    out = torch.empty(n, dtype=torch.int64, device=records.device)
+    with torch.cuda.device(records.device):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _check(lib().acm_gpu_pack_records_device(records.data_ptr(), n, pos_lo, pb, lb, out.data_ptr(), st), "acm_gpu_pack_records_device")
+    return out
+
+
+def unpack_records(packed, wire, out):
+    """acm_gpu_unpack_records_device: int64 [n] CUDA tensor -> the records, into `out` (int64 [n, 2], same device)."""
+    import torch
+    pos_lo, pb, lb = wire
+    assert packed.is_cuda and out.is_cuda and out.shape[0] == packed.shape[0] and out.is_contiguous()
+    with torch.cuda.device(out.device):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _check(lib().acm_gpu_unpack_records_device(packed.data_ptr(), packed.shape[0], pos_lo, pb, lb, out.data_ptr(), st), "acm_gpu_unpack_records_device")
+    return out
 
 
 class MultiScan:

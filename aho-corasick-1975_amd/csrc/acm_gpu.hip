@@ -2867,6 +2867,52 @@ acm_gpu_scan_host (ACMPlan *plan, const void *text, uint64_t n_symbols, uint64_t
 #undef HOST_TRY
 }
 
+/* ------------------------------------------------------------------ records on the wire (include/acm_gpu.h) */
+extern "C" int
+acm_gpu_wire_bits (const ACMPlan *plan, uint64_t span, uint32_t *pos_bits, uint32_t *len_bits, uint32_t *kw_bits) {
+  if (!plan || !pos_bits || !len_bits || !kw_bits)
+    return ACM_GPU_E_ARG;
+  auto bits = [] (uint64_t v) { /* bits that hold every value in [0, v] */
+    uint32_t b = 1;
+    while (b < 64 && (v >> b))
+      b++;
+    return b;
+  };
+  const uint64_t kw_max = (uint64_t)plan->covered_keywords + plan->finfo.n_keywords + plan->kw_base; /* (an upper bound: a delta's ids follow the plan's) */
+  *pos_bits = bits (span ? span - 1 : 0);
+  *len_bits = bits (plan->finfo.lmax);
+  *kw_bits = bits (kw_max);
+  return *pos_bits + *len_bits + *kw_bits <= 64 ? ACM_GPU_OK : ACM_GPU_E_INELIGIBLE;
+}
+
+extern "C" int
+acm_gpu_pack_records_device (const ACMRecord *d_records, uint64_t n, uint64_t pos_lo, uint32_t pos_bits, uint32_t len_bits, uint64_t *d_packed,
+                             void *stream) {
+  if ((n && (!d_records || !d_packed)) || pos_bits == 0 || pos_bits + len_bits >= 64)
+    return ACM_GPU_E_ARG;
+  if (n == 0)
+    return ACM_GPU_OK;
+  const uint64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL (pack_records_kernel, dim3 ((uint32_t)(blocks < 16384 ? blocks : 16384)), dim3 (256), 0, static_cast<hipStream_t> (stream), d_records, n,
+                      pos_lo, pos_bits, len_bits, d_packed);
+  HIP_TRY (hipGetLastError ());
+  return ACM_GPU_OK;
+}
+
+extern "C" int
+acm_gpu_unpack_records_device (const uint64_t *d_packed, uint64_t n, uint64_t pos_lo, uint32_t pos_bits, uint32_t len_bits, ACMRecord *d_records,
+                               void *stream) {
+  if ((n && (!d_records || !d_packed)) || pos_bits == 0 || pos_bits + len_bits >= 64)
+    return ACM_GPU_E_ARG;
+  if (n == 0)
+    return ACM_GPU_OK;
+  const uint64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL (unpack_records_kernel, dim3 ((uint32_t)(blocks < 16384 ? blocks : 16384)), dim3 (256), 0, static_cast<hipStream_t> (stream), d_packed, n,
+                      pos_lo, pos_bits, len_bits, d_records);
+  HIP_TRY (hipGetLastError ());
+  return ACM_GPU_OK;
+}
+
 /* ------------------------------------------------------------------ several GPUs, one process (include/acm_gpu.h)
  * contiguous shards, an lmax - 1 halo, tables replicated, no collective on the data
  * path; the one exchange step is the gather of the ordered records on devices[0] by direct peer
@@ -2890,6 +2936,12 @@ struct ACMMulti {
   };
   std::vector<ShardBuf> buf; /* per shard */
   uint64_t *h_found = nullptr; /* pinned, one count per shard */
+  /* records on the wire: a shard of another device packs its ordered records to 8 bytes each
+   * (acm_gpu_pack_records_device), sends them to this staging area on devices[0], and they are
+   * unpacked into their place there -- half the bytes over the shard's one link to the root */
+  uint64_t *stage0 = nullptr;
+  uint64_t stage0_cap = 0; /* in 8-byte words */
+  std::vector<hipEvent_t> arrived; /* per shard: its packed records have landed on devices[0] */
   int slot_of (int device) const {
     for (size_t i = 0; i < distinct.size (); i++)
       if (distinct[i] == device)
@@ -2919,6 +2971,15 @@ acm_gpu_multi_destroy (ACMMulti *mu) {
   }
   if (mu->h_found)
     (void)hipHostFree (mu->h_found);
+  if (mu->stage0) {
+    (void)hipSetDevice (mu->dev[0]);
+    (void)hipFree (mu->stage0);
+  }
+  for (size_t r = 0; r < mu->arrived.size (); r++)
+    if (mu->arrived[r]) {
+      (void)hipSetDevice (mu->dev[r]);
+      (void)hipEventDestroy (mu->arrived[r]);
+    }
   delete mu;
 }
 
@@ -3117,17 +3178,57 @@ multi_scan (ACMMulti *mu, const void *const *d_text, uint64_t n, ACMRecord *d_ou
   *n_found = total;
   if (total > capacity)
     return ACM_GPU_E_OVERFLOW;
-  /* (every shard's records are in canonical order where they are:) each shard's run into its place on devices[0] */
-  uint64_t off = 0;
+  /* (every shard's records are in canonical order where they are:) each shard's run into its place
+   * on devices[0] -- from another device as 8-byte words when the fields fit (acm_gpu_wire_bits):
+   * packed into the shard's scratch, sent to the staging area, unpacked there behind an event */
+  const char *wire_env = getenv ("ACM_GPU_WIRE"); /* 0: 16-byte records over the links; 2: the wire form for shards of devices[0] too (tests on one GPU) */
+  const bool wire_off = wire_env && atoi (wire_env) == 0, wire_all = wire_env && atoi (wire_env) == 2;
+  uint64_t remote = 0;
+  for (size_t r = 0; r < R; r++)
+    if (mu->dev[r] != mu->dev[0] || wire_all)
+      remote += mu->h_found[r];
+  if (remote > mu->stage0_cap && !wire_off) {
+    MULTI_TRY (hipSetDevice (mu->dev[0]));
+    if (mu->stage0)
+      MULTI_TRY (hipFree (mu->stage0));
+    mu->stage0 = nullptr;
+    mu->stage0_cap = 0;
+    MULTI_TRY (hipMalloc (reinterpret_cast<void **> (&mu->stage0), remote * 8));
+    mu->stage0_cap = remote;
+  }
+  if (mu->arrived.size () < R)
+    mu->arrived.resize (R, nullptr);
+  uint64_t off = 0, soff = 0;
   for (size_t r = 0; r < R; r++) {
     const Shard &s = sh[r];
     const uint64_t found = mu->h_found[r];
     MULTI_TRY (hipSetDevice (mu->dev[r]));
     hipStream_t st = mu->stream[s.slot];
     if (found) {
-      if (mu->dev[r] == mu->dev[0])
+      uint32_t pb = 0, lb = 0, kb = 0;
+      if (mu->dev[r] == mu->dev[0] && !wire_all)
         MULTI_TRY (hipMemcpyAsync (d_out + off, mu->buf[r].rec, found * sizeof (ACMRecord), hipMemcpyDeviceToDevice, st));
-      else
+      else if (!wire_off && acm_gpu_wire_bits (mu->plan[s.slot], s.e - s.rb, &pb, &lb, &kb) == ACM_GPU_OK && found * 8 <= mu->buf[r].tmp_cap) {
+        uint64_t *packed = static_cast<uint64_t *> (mu->buf[r].tmp); /* (the scan's scratch: it is done with it) */
+        rc = acm_gpu_pack_records_device (mu->buf[r].rec, found, s.rb, pb, lb, packed, st);
+        if (!rc) {
+          MULTI_TRY (hipMemcpyPeerAsync (mu->stage0 + soff, mu->dev[0], packed, mu->dev[r], found * 8, st));
+          if (!mu->arrived[r])
+            MULTI_TRY (hipEventCreateWithFlags (&mu->arrived[r], hipEventDisableTiming));
+          MULTI_TRY (hipEventRecord (mu->arrived[r], st));
+          MULTI_TRY (hipSetDevice (mu->dev[0]));
+          MULTI_TRY (hipStreamWaitEvent (mu->stream[0], mu->arrived[r], 0));
+          rc = acm_gpu_unpack_records_device (mu->stage0 + soff, found, s.rb, pb, lb, d_out + off, mu->stream[0]);
+        }
+        if (rc) {
+          for (size_t i = 0; i < mu->distinct.size (); i++) {
+            (void)hipSetDevice (mu->distinct[i]);
+            (void)hipStreamSynchronize (mu->stream[i]);
+          }
+          return rc;
+        }
+        soff += found;
+      } else
         MULTI_TRY (hipMemcpyPeerAsync (d_out + off, mu->dev[0], mu->buf[r].rec, mu->dev[r], found * sizeof (ACMRecord), st));
     }
     off += found;

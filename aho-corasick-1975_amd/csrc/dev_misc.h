@@ -134,6 +134,32 @@ struct Rec16 {
   uint64_t a, b;
 };
 
+/* ------------------------------------------------------------------ records on the wire (include/acm_gpu.h: acm_gpu_pack_records_device)
+ * A shard's ordered records hold far less than their 16 bytes: end positions within the shard's
+ * range, lengths up to lmax, ids below the number of keywords.  Packed to 8 bytes --
+ * (end_pos - pos_lo) | length << pos_bits | keyword_id << (pos_bits + len_bits) -- they are what a
+ * shard sends to the root over its one xGMI link; the root unpacks them where they belong.  Two
+ * records per thread and load / store instruction on the 16-byte side. */
+__global__ void
+pack_records_kernel (const ACMRecord *__restrict__ rec, uint64_t n, uint64_t pos_lo, uint32_t pos_bits, uint32_t len_bits, uint64_t *__restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint4 r = *reinterpret_cast<const uint4 *> (rec + i);
+    const uint64_t pos = (((uint64_t)r.y << 32) | r.x) - pos_lo;
+    out[i] = pos | ((uint64_t)r.z << pos_bits) | ((uint64_t)r.w << (pos_bits + len_bits));
+  }
+}
+__global__ void
+unpack_records_kernel (const uint64_t *__restrict__ in, uint64_t n, uint64_t pos_lo, uint32_t pos_bits, uint32_t len_bits, ACMRecord *__restrict__ rec) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t pmask = (1ull << pos_bits) - 1, lmask = (1ull << len_bits) - 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t v = in[i];
+    const uint64_t pos = (v & pmask) + pos_lo;
+    *reinterpret_cast<uint4 *> (rec + i) = make_uint4 ((uint32_t)pos, (uint32_t)(pos >> 32), (uint32_t)((v >> pos_bits) & lmask), (uint32_t)(v >> (pos_bits + len_bits)));
+  }
+}
+
 /* ------------------------------------------------------------------ synthetic text */
 __device__ __forceinline__ uint64_t
 splitmix64 (uint64_t x) {

@@ -220,7 +220,8 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
         def e2e():     # acm_gpu_scan_ordered_device: scan + order queued together, ONE wait (for the count) at the end
             _, _, order_tmp[0] = plan.scan_ordered(text, n_scan, emit_from=halo, pos_base=pos_base, records=records, count=count, tmp=order_tmp[0])
             n = int(count.item())
-            return acm.sharded.gather_records(records[:n], dst=0) if world > 1 else records[:n]
+            # (the records travel as 8-byte words when their fields fit: Plan.wire / acm_gpu_pack_records_device)
+            return acm.sharded.gather_records(records[:n], dst=0, wire=plan.wire(n_scan, pos_base)) if world > 1 else records[:n]
 
         gathered = e2e()
         barrier()

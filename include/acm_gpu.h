@@ -240,6 +240,20 @@ size_t acm_gpu_order_tmp_bytes (const ACMPlan *plan, uint64_t n, uint64_t span);
 int acm_gpu_order_records_device (ACMPlan *plan, ACMRecord *d_records, uint64_t n, uint64_t pos_lo, uint64_t span,
                                   void *d_tmp, size_t tmp_bytes, void *stream);
 
+/* Records on the wire.  The records of a scan of `span` symbols with pos_base = pos_lo hold
+ * positions in [pos_lo, pos_lo + span), lengths up to the plan's lmax and ids below its number of
+ * keywords: when that fits 64 bits (acm_gpu_wire_bits returns 0 and the three field widths; config
+ * 4's shards: 34 + 4 + 17) a record packs to ONE 8-byte word,
+ *     (end_pos - pos_lo) | length << pos_bits | keyword_id << (pos_bits + len_bits),
+ * half of what a shard sends to the root in a multi-GPU scan (acm_gpu_multi_* and sharded.py pack
+ * behind the canonical order and unpack on the root; the order is kept: index i stays index i).
+ * Asynchronous on `stream`; d_packed / d_records on the current device of the call. */
+int acm_gpu_wire_bits (const ACMPlan *plan, uint64_t span, uint32_t *pos_bits, uint32_t *len_bits, uint32_t *kw_bits);
+int acm_gpu_pack_records_device (const ACMRecord *d_records, uint64_t n, uint64_t pos_lo, uint32_t pos_bits, uint32_t len_bits,
+                                 uint64_t *d_packed, void *stream);
+int acm_gpu_unpack_records_device (const uint64_t *d_packed, uint64_t n, uint64_t pos_lo, uint32_t pos_bits, uint32_t len_bits,
+                                   ACMRecord *d_records, void *stream);
+
 /* acm_gpu_scan_device and the canonical order of what it found in ONE call that only queues work on
  * `stream`: the order passes read the number of records from *d_count on the device, so no host
  * round trip separates the scan from them (the caller loop of aho_corasick.h:47,77 yields its

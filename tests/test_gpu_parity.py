@@ -877,11 +877,57 @@ def test_multi_device_scan_c_abi_eight_shards_on_one_gpu(torch_cuda):
     tiny = text[:5]
     assert np.array_equal(mu.scan_host(tiny), o.scan(tiny))
     assert mu.scan_host(text[:0]).size == 0
+    # a second call on the same handle re-uses the shards' buffers (grow-only): the same records
+    rec.zero_()
+    assert mu.scan_device(shards, n, rec) == want_n
+    assert acm.synth.device_digest(rec, want_n) == (want_n, want_d)
     mu.close()
     one = acm.MultiScan(m, [0])
     part = text[:1 << 20]
     assert np.array_equal(one.scan_host(part), o.scan(part))
     one.close()
+
+
+def test_records_on_the_wire_as_eight_byte_words(torch_cuda, monkeypatch):
+    """acm_gpu_wire_bits / acm_gpu_pack_records_device / acm_gpu_unpack_records_device: what a shard
+    sends to the root in a multi-GPU scan.  Round trip of a scan's ordered records (bit for bit, with
+    a position base beyond 2^40), the field widths of config 4's shards, and the multi-device entry
+    with the wire form forced for the shards of the root device too (ACM_GPU_WIRE=2: on one GPU the
+    pack -> copy -> unpack path runs for all eight shards) against the oracle."""
+    torch = torch_cuda
+    kd, ko = acm.synth.keywords(100000)
+    m = acm.Machine(1)
+    m.add_keywords_packed(kd, ko)
+    o = po.Oracle(1, po.AC75)
+    o.add_keywords_packed(kd, ko)
+    plan = m.plan(0)
+    w4 = plan.wire(1 << 34, 5 << 34)
+    assert w4 is not None and w4[1:] == (34, 4)            # 2^34 positions, lengths up to 12; 17 bits of keyword id on top
+    n = (16 << 20) + 777
+    text = acm.synth.text((n + 4095) // 4096 * 4096, kd, ko)[:n]
+    dev = torch.from_numpy(text).cuda()
+    base = (1 << 41) + 4096
+    rec, cnt, _ = plan.scan_ordered(dev, pos_base=base, capacity=n // 16)
+    k = int(cnt.item())
+    want_n, want_d = o.scan_mt(text, 8)
+    assert k == want_n
+    wire = plan.wire(n, base)
+    assert wire == (base, 25, 4)
+    packed = acm.binding.pack_records(rec[:k], wire)
+    assert packed.shape == (k,) and packed.dtype == torch.int64
+    back = torch.zeros((k, 2), dtype=torch.int64, device="cuda")
+    acm.binding.unpack_records(packed, wire, back)
+    assert torch.equal(back, rec[:k])
+    assert int((packed & ((1 << 25) - 1)).max().item()) < n and bool((packed[1:] & ((1 << 25) - 1) >= packed[:-1] & ((1 << 25) - 1)).all().item())
+    # fields that do not fit 64 bits: no wire form (2^60 positions + 4 + 17 bits)
+    assert plan.wire(1 << 60, 0) is None
+    monkeypatch.setenv("ACM_GPU_WIRE", "2")
+    mu = acm.MultiScan(m, [0] * 8)
+    got = mu.scan_host(text)
+    assert got.size == want_n and po.digest(got) == want_d and np.all(np.diff(got["end_pos"].astype(np.int64)) >= 0)
+    head = o.scan(text[:1 << 20])
+    assert np.array_equal(got[:head.size], head)
+    mu.close()
 
 
 def _gloo_gpu_worker(rank, world, port, n, K, out_path):
@@ -906,7 +952,8 @@ def _gloo_gpu_worker(rank, world, port, n, K, out_path):
         rec = plan.scan_sorted(text, emit_from=emit_from, pos_base=pos_base)
         return torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.int64).reshape(-1, 2).copy()).cuda()
 
-    got = acm.sharded.scan_sharded(scan_fn, n, m.lmax, make_shard)
+    # (the records of rank 1 travel as 8-byte words: packed on its device, unpacked on rank 0's)
+    got = acm.sharded.scan_sharded(scan_fn, n, m.lmax, make_shard, wire_fn=plan.wire)
     if rank == 0:
         np.save(out_path, got.cpu().numpy())
     else:
