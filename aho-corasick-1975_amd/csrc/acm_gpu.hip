@@ -108,6 +108,8 @@ struct ACMPlan {
   bool gram = false; /* 4-gram sieve kernel instead of the sticky dense walk */
   bool gram_shorts = false, gram_wide = false;
   bool gram2 = false; /* scan_gram2_kernel (dev_gram2.h) instead of scan_gram_kernel */
+  bool short_pass = false; /* narrow alphabets: the keywords of 1-3 symbols in a pass of their own (scan_short_kernel, dev_short.h) */
+  uint32_t short_lds_bytes = 0;
   uint32_t gram_lds_bytes = 0;
   uint32_t class_sym_bytes = 0; /* comparator-class plans: the symbol size they were made for */
   bool sparse = false, sparse_lut_lds = false, starts_lut_lds = false;
@@ -277,18 +279,16 @@ gram_kernel_ptr (bool count_only, bool shorts, bool wide, bool tiled = false, bo
       return reinterpret_cast<const void *> (&scan_gram2_kernel<false, true>);
     return count_only ? reinterpret_cast<const void *> (&scan_gram2_kernel<true, false>) : reinterpret_cast<const void *> (&scan_gram2_kernel<false, false>);
   }
+  /* (keywords of 1-3 symbols inside the kernel: hashed windows only -- narrow alphabets give them a
+   * pass of their own, scan_short_kernel; the instantiations that did both spilled 140 to 320 vector registers) */
   if (tiled) /* (narrow alphabets, record mode) */
-    return shorts ? reinterpret_cast<const void *> (&scan_gram_kernel<false, true, false, true>)
-                  : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, false, true>);
+    return reinterpret_cast<const void *> (&scan_gram_kernel<false, false, false, true>);
   if (wide && shorts)
     return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, true, true, false>)
                       : reinterpret_cast<const void *> (&scan_gram_kernel<false, true, true, false>);
   if (wide)
     return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, false, true, false>)
                       : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, true, false>);
-  if (shorts)
-    return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, true, false, false>)
-                      : reinterpret_cast<const void *> (&scan_gram_kernel<false, true, false, false>);
   return count_only ? reinterpret_cast<const void *> (&scan_gram_kernel<true, false, false, false>)
                     : reinterpret_cast<const void *> (&scan_gram_kernel<false, false, false, false>);
 }
@@ -740,7 +740,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     any_short |= fv.depth[fv.kw_state[k]] < 4;
   const bool gram_big = dense && (entry_bytes == 4 || gram_mode >= 2 || rowless_share > 0.001) && gram_mode != 0 &&
                         fi.lmax >= 4 && n < 0x40000000u;
-  bool gram_shorts = gram_big && any_short; /* keywords of 1-3 symbols: the kernel's nibble table and third queue */
+  bool gram_shorts = gram_big && any_short; /* keywords of 1-3 symbols: a nibble per 3-gram + their ids (narrow alphabets: a pass of their own, scan_short_kernel; hashed windows: the kernel's third queue) */
   /* wide alphabets: hashed 4-byte windows instead of the exact base-W index */
   const bool gram_wide = gram_big && !gram_narrow;
   bool gram = gram_big;
@@ -773,7 +773,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const char *bloom_env = getenv ("ACM_GPU_BLOOM"); /* 0: no Bloom filters (experiments) */
   if (gram && !gram_wide && n_depth4 >= 2048 && !(bloom_env && atoi (bloom_env) == 0)) {
     const uint32_t lds_cap = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
-    const uint32_t gq_bytes = (SPARSE_THREADS / WAVE) * ((gram_shorts ? QCAP : 0u) + GRAM_Q1 + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
+    const uint32_t gq_bytes = (SPARSE_THREADS / WAVE) * ((gram_shorts && gram_wide ? QCAP : 0u) + GRAM_Q1 + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
     bloom_off = (g3_off + g3_bytes + 15) & ~15u;
     const uint64_t used = (uint64_t)bloom_off + gq_bytes + WALK_CTX_BYTES + 64;
     uint32_t n_term4 = 0, n_5 = 0;
@@ -801,7 +801,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const uint32_t tab2_words = gram && !gram_wide ? (gW4 + 15) / 16 : 0;
   const uint32_t g2_off = (tab2_words * 4 + 15) & ~15u;
   const char *gram2_env = getenv ("ACM_GPU_GRAM2");
-  const bool gram2 = gram && !gram_wide && !gram_shorts && !(gram2_env && atoi (gram2_env) == 0) &&
+  const bool gram2 = gram && !gram_wide && !(gram2_env && atoi (gram2_env) == 0) &&
                      (uint64_t)g2_off + G2_LDS_FIXED <= ((uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160u * 1024 : 64u * 1024);
   const size_t o_g4bits = blob_reserve (cur, gram ? (size_t)(bloom5_bits ? bloom_off + bloom_bytes : g3_off + g3_bytes) + 16 : 0);
   const size_t o_g3rec = blob_reserve (cur, gram_shorts && !gram_wide ? (size_t)gW3 * 16 : 0);
@@ -980,7 +980,7 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   p->d_dstart = u32p (o_dstart);
   if (gram) {
     const uint32_t lds_total = (uint32_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
-    const uint32_t gq = (SPARSE_THREADS / WAVE) * ((gram_shorts ? QCAP : 0u) + GRAM_Q1 + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
+    const uint32_t gq = (SPARSE_THREADS / WAVE) * ((gram_shorts && gram_wide ? QCAP : 0u) + GRAM_Q1 + GRAM_Q2 + (gram_wide ? HITS_STRIDE : 0u)) * 8;
     const uint32_t bits_bytes = bloom5_bits ? bloom_off + bloom_bytes : g3_off + g3_bytes;
     if ((uint64_t)bits_bytes + gq + WALK_CTX_BYTES <= lds_total) {
       p->d_kw4 = u32p (o_kw4);
@@ -1011,7 +1011,9 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
       p->GK.stab = reinterpret_cast<const uint2 *> (b + o_stab);
       p->GK.stab_log2 = stab_log2;
       p->GK.short_lens = short_lens;
-      p->gram_shorts = gram_shorts;
+      p->gram_shorts = gram_shorts && gram_wide; /* (the kernel's own short-keyword path: hashed windows only) */
+      p->short_pass = gram_shorts && !gram_wide;
+      p->short_lds_bytes = ((g3_bytes + 15) & ~15u) + SH_LDS_FIXED;
       p->gram_wide = gram_wide;
       p->GK.W = gW;
       p->GK.lo = fi.alpha_lo;
@@ -1316,7 +1318,7 @@ acm_gpu_plan_info (const ACMPlan *plan, ACMPlanInfo *info) {
   info->delta_keywords = plan->delta ? plan->delta->finfo.n_keywords : 0;
   info->merges = plan->merges;
   info->records_direct = ((plan->gram && !plan->gram_wide) || plan->info.kernel == 2) ? 1u : 0u;
-  info->variant = plan->gram2 ? 2u : 0u;
+  info->variant = (plan->gram2 ? 2u : 0u) | (plan->short_pass ? 4u : 0u);
 }
 
 extern "C" int
@@ -1573,6 +1575,49 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t 
   return ACM_GPU_OK;
 }
 
+/* the keywords of 1-3 symbols of a 4-gram plan over a narrow alphabet: a pass of their own over the
+ * segment (dev_short.h), into the same record buffer; its waves' holes have descriptors of their own */
+template <bool COUNT_ONLY>
+int
+launch_short (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop, bool first_segment, bool last_segment) {
+  uint32_t grid = (uint32_t)p->cu_count;
+  const uint32_t wpb = SPARSE_THREADS / WAVE;
+  /* a match of 1-3 symbols that ends at emit_from or later starts no earlier than emit_from - 2 */
+  const uint32_t group = WAVE * 16;
+  const uint32_t ngroups = (uint32_t)(((uint64_t)a.n + group - 1) / group);
+  const uint32_t first_group = (a.emit_from > 2 ? a.emit_from - 2 : 0) / group;
+  uint64_t R = (ngroups - first_group) / ((uint64_t)grid * wpb * 16);
+  R = R < GRAM_R_MIN ? GRAM_R_MIN : (R > 64 ? 64 : R);
+  GramK K = p->GK;
+  K.R = (uint32_t)R;
+  a.range_begin = first_group / (uint32_t)R;
+  a.range_end = (uint32_t)((ngroups + R - 1) / R);
+  const uint32_t tiles = a.range_end - a.range_begin;
+  if ((tiles + wpb - 1) / wpb < grid)
+    grid = (tiles + wpb - 1) / wpb;
+  set_tile_pool (p, a, grid * wpb);
+  RecHole *holes = COUNT_ONLY ? nullptr : static_cast<RecHole *> (p->d_holes) + p->direct_regions;
+  uint32_t resume = first_segment ? 0u : 1u;
+  if (holes && first_segment)
+    HIP_TRY (hipMemsetAsync (holes, 0, (size_t)p->direct_regions * sizeof (RecHole), st));
+  void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &holes, &resume };
+  HIP_TRY (hipLaunchKernel (COUNT_ONLY ? reinterpret_cast<const void *> (&scan_short_kernel<true>) : reinterpret_cast<const void *> (&scan_short_kernel<false>),
+                            dim3 (grid), dim3 (SPARSE_THREADS), args, p->short_lds_bytes, st));
+  if (stop)
+    HIP_TRY (hipEventRecord (stop, st));
+  if (!COUNT_ONLY && last_segment) {
+    const uint32_t n_waves = p->direct_regions;
+    uint32_t npow = 64;
+    while (npow < n_waves)
+      npow <<= 1;
+    const uint32_t blocks = n_waves / 16 > 0 ? n_waves / 16 : 1;
+    hipLaunchKernelGGL (close_holes_kernel, dim3 (blocks), dim3 (CLOSE_THREADS), npow * 16, st, E, holes, n_waves, npow,
+                        reinterpret_cast<unsigned int *> (p->d_total + 1));
+    HIP_TRY (hipGetLastError ());
+  }
+  return ACM_GPU_OK;
+}
+
 template <bool COUNT_ONLY>
 int
 launch_csr (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st) {
@@ -1665,7 +1710,7 @@ ensure_direct_buffers (ACMPlan *p) {
   if (p->d_spill)
     HIP_TRY (hipFree (p->d_spill));
   p->d_holes = p->d_spill = nullptr;
-  if (hipMalloc (&p->d_holes, (size_t)regions * sizeof (RecHole)) != hipSuccess ||
+  if (hipMalloc (&p->d_holes, (size_t)regions * 2 * sizeof (RecHole)) != hipSuccess || /* (the 4-gram pass's and the short-keyword pass's) */
       hipMalloc (&p->d_spill, (size_t)regions * REC_CHUNK * 16) != hipSuccess)
     return ACM_GPU_E_NOMEM;
   p->direct_regions = regions;
@@ -2229,6 +2274,29 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
       return rc;
     }
   }
+  /* narrow alphabets: the keywords of 1-3 symbols, a pass of their own over the same segments
+   * (dev_short.h); their records follow the 4-gram pass' in the same buffer */
+  for (uint64_t seg = first_seg; p->gram && p->short_pass && !use_dense && seg < n; seg += SEG) {
+    const uint64_t seg_end = seg + SEG < n ? seg + SEG : n;
+    const uint64_t read_begin = seg > 16 ? seg - 16 : 0; /* (a halo of 2 symbols would do: 16 keeps the alignment) */
+    Launch a{};
+    a.text = static_cast<const unsigned char *> (d_text) + read_begin * sb;
+    a.n = (uint32_t)(seg_end - read_begin);
+    const uint64_t ef = emit_from > seg ? emit_from : seg;
+    a.emit_from = (uint32_t)(ef - read_begin);
+    E.pos_base = pos_base + read_begin;
+    E.text = a.text;
+    E.n = a.n;
+    E.emit_from = a.emit_from;
+    hipEvent_t stop, stop_all;
+    int rc = timing_begin (p, st, &stop, &stop_all);
+    if (!rc)
+      rc = launch_short<COUNT_ONLY> (p, E, a, st, stop, seg == first_seg, seg_end == n);
+    if (!rc && stop_all)
+      HIP_TRY (hipEventRecord (stop_all, st));
+    if (rc)
+      return rc;
+  }
   return ACM_GPU_OK;
 }
 
@@ -2670,8 +2738,8 @@ tiled_layout (const ACMPlan *p, uint64_t capacity, uint64_t n, uint64_t emit_fro
   const char *env = getenv ("ACM_GPU_ORDER"); /* radix / buckets: not this way (experiments, tests) */
   if (env && (strcmp (env, "radix") == 0 || strcmp (env, "buckets") == 0))
     return L;
-  if (!p->gram || p->gram_wide || p->delta || p->finfo.lmax > WAVE * 16 || p->finfo.n_edges == 0)
-    return L;
+  if (!p->gram || p->gram_wide || p->short_pass || p->delta || p->finfo.lmax > WAVE * 16 || p->finfo.n_edges == 0)
+    return L; /* (a second pass' records do not lie tile by tile: the general order passes) */
   if (n == 0 || emit_from >= n || capacity == 0 || capacity >= (1ull << 31))
     return L;
   const uint64_t halo = p->finfo.lmax > 1 ? (((uint64_t)p->finfo.lmax - 1 + 15) / 16) * 16 : 0;

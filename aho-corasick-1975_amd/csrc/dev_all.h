@@ -132,6 +132,7 @@ constexpr uint32_t IT_OUT = 1u << 29;   /* report the outputs of the state itsel
 #include "dev_starts.h"
 #include "dev_gram.h"
 #include "dev_gram2.h"
+#include "dev_short.h"
 #include "dev_misc.h"
 #include "dev_order.h"
 #include "dev_tiles.h"

@@ -201,7 +201,12 @@ expand_hits_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint32
  * wave), which the closing pass reads from -- so nothing is dropped because of holes.
  * Per wave in LDS (WaveRec): where slot 0 of the current chunk is (in the caller's buffer or in the
  * spill area), the chunk's first slot, and how many slots the fast path may use. */
-constexpr uint32_t REC_CHUNK = 1024;
+#ifndef ACM_REC_CHUNK
+#define ACM_REC_CHUNK 1024
+#endif
+constexpr uint32_t REC_CHUNK = ACM_REC_CHUNK;
+constexpr uint32_t HOLE_BITS = 13; /* close_holes_kernel's sort keys: first slot << HOLE_BITS | length */
+static_assert (REC_CHUNK < (1u << HOLE_BITS) && REC_CHUNK % 1024 == 0, "a hole's length fits its key");
 struct WaveRec {
   uint32_t dst_lo, dst_hi;   /* address of slot 0 of the current chunk (meaningless while limit == 0) */
   uint32_t base_lo, base_hi; /* index of that slot */
@@ -299,7 +304,7 @@ emit_records_slow (const EmitCtx *Ep, WaveRec *W, uint32_t used, bool hit, uint3
  * the filled slots of [0, T) and there are C = T - H of them; those at C or beyond (in the
  * caller's buffer or, past its capacity, in the spill area) move into the holes below C, the k-th
  * hole slot taking the k-th such record, and the counter is rewound to C.
- * Every block sorts the holes by first slot in LDS (bitonic, <= 4,096 keys of start << 11 | length),
+ * Every block sorts the holes by first slot in LDS (bitonic, <= 4,096 keys of start << HOLE_BITS | length),
  * takes their prefix sums P, and handles the holes b, b + gridDim.x, ...: target = start_i + t is
  * hole slot number k = P[i] + t; its source is the filled slot of rank (C - M) + k (M = hole slots
  * below C), found by bisection on G[i] = start_i - P[i] = filled slots in front of hole i. */
@@ -313,13 +318,14 @@ close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t 
   __shared__ uint32_t s_part[CLOSE_THREADS / WAVE];
   __shared__ uint32_t s_M;
   const uint32_t tid = threadIdx.x;
-  constexpr unsigned long long PAD = ~0ull << 11;
+  constexpr unsigned long long PAD = ~0ull << HOLE_BITS;
+  constexpr uint32_t HOLE_MASK = (1u << HOLE_BITS) - 1;
   for (uint32_t i = tid; i < npow; i += CLOSE_THREADS) {
     unsigned long long k = PAD;
     if (i < n_waves) {
       const RecHole h = holes[i];
       if (h.len)
-        k = (((unsigned long long)h.start_hi << 32 | h.start_lo) << 11) | h.len;
+        k = (((unsigned long long)h.start_hi << 32 | h.start_lo) << HOLE_BITS) | h.len;
     }
     key[i] = k;
   }
@@ -347,7 +353,7 @@ close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t 
   for (uint32_t q = 0; q < per; q++) {
     const uint32_t i = tid * per + q;
     if (i < npow)
-      run += (uint32_t)(key[i] & 2047u);
+      run += (uint32_t)(key[i] & HOLE_MASK);
   }
   const uint32_t incl = wave_incl_scan (run);
   if ((tid & (WAVE - 1)) == WAVE - 1)
@@ -369,7 +375,7 @@ close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t 
       const uint32_t i = tid * per + q;
       if (i < npow) {
         P[i] = acc;
-        acc += (uint32_t)(key[i] & 2047u);
+        acc += (uint32_t)(key[i] & HOLE_MASK);
       }
     }
   }
@@ -378,8 +384,8 @@ close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t 
   /* M: hole slots below C */
   uint32_t mine = 0;
   for (uint32_t i = tid; i < npow; i += CLOSE_THREADS) {
-    const unsigned long long st = key[i] >> 11;
-    const uint32_t len = (uint32_t)(key[i] & 2047u);
+    const unsigned long long st = key[i] >> HOLE_BITS;
+    const uint32_t len = (uint32_t)(key[i] & HOLE_MASK);
     if (len && st < C)
       mine += C - st < len ? (uint32_t)(C - st) : len;
   }
@@ -397,8 +403,8 @@ close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t 
   __syncthreads ();
   const unsigned long long first_rank = C - s_M; /* rank (among the filled slots) of the first record at C or beyond */
   for (uint32_t i = blockIdx.x; i < npow; i += gridDim.x) {
-    const unsigned long long st = key[i] >> 11;
-    const uint32_t len = (uint32_t)(key[i] & 2047u);
+    const unsigned long long st = key[i] >> HOLE_BITS;
+    const uint32_t len = (uint32_t)(key[i] & HOLE_MASK);
     if (!len || st >= C)
       continue;
     const uint32_t clipped = C - st < len ? (uint32_t)(C - st) : len;
@@ -408,8 +414,8 @@ close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t 
       uint32_t lo = 0, hi = npow;
       while (lo < hi) {
         const uint32_t mid = (lo + hi) / 2;
-        const unsigned long long g = (key[mid] >> 11) - P[mid];
-        if ((key[mid] & 2047u) != 0 ? g <= r : false) /* (the padding sorts last and is in front of nothing) */
+        const unsigned long long g = (key[mid] >> HOLE_BITS) - P[mid];
+        if ((key[mid] & HOLE_MASK) != 0 ? g <= r : false) /* (the padding sorts last and is in front of nothing) */
           lo = mid + 1;
         else
           hi = mid;

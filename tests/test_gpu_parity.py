@@ -1535,6 +1535,8 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
         assert plan.info.dense_rows > 32768, "the generator is meant to give more states than the LDS scheme takes"
     if kind in ("gram", "gramold", "gram26", "gram30"):
         assert plan.info.variant == (2 if kind in ("gram", "gram26") else 0), (kind, plan.info.variant)
+    if kind == "short":     # keywords of 1-3 symbols: a pass of their own (scan_short_kernel) behind the 4-gram kernel
+        assert plan.info.variant == 2 | 4, plan.info.variant
     if kind == "dense":     # small dictionaries whose hot rows outgrow LDS go to the 4-gram kernel by themselves
         assert plan.info.kernel in (1, 5, 6), plan.info.kernel
     else:
