@@ -109,7 +109,9 @@ struct ACMPlan {
   bool gram_shorts = false, gram_wide = false;
   bool gram2 = false; /* scan_gram2_kernel (dev_gram2.h) instead of scan_gram_kernel */
   bool short_pass = false; /* narrow alphabets: the keywords of 1-3 symbols in a pass of their own (scan_short_kernel, dev_short.h) */
-  uint32_t short_lds_bytes = 0;
+  uint32_t short_lds_bytes = 0, short_lds_count_bytes = 0; /* scan_short_kernel: with records / count-only (the nibbles alone) */
+  bool short_ids_lds = false; /* scan_short_kernel: the keyword ids are in LDS (else read by rank from the image in HBM) */
+  uint32_t short_blocks_per_cu = 1; /* scan_short_kernel, count-only: two blocks a CU when its LDS allows (8 waves a SIMD) */
   uint32_t gram_lds_bytes = 0;
   uint32_t class_sym_bytes = 0; /* comparator-class plans: the symbol size they were made for */
   bool sparse = false, sparse_lut_lds = false, starts_lut_lds = false;
@@ -159,6 +161,7 @@ struct ACMPlan {
   /* 4-gram kernel, narrow alphabets (records straight from the scan kernel): one hole descriptor
    * per wave and the spill area, one chunk of records per wave (64 MB on 256 CUs) */
   void *d_holes = nullptr, *d_spill = nullptr;
+  uint32_t spill_chunk = 0; /* slots per chunk the spill area was sized for */
   uint32_t direct_regions = 0;
   /* a tiled scan in progress (acm_gpu_scan_ordered_device -> scan_tiled): the 4-gram kernel writes
    * a TileEntry per tile from tiled_dir[tiled_base] on and links its chunks in tiled_prev */
@@ -270,6 +273,13 @@ starts_fn (bool lut_lds, bool count_only) {
                       : reinterpret_cast<const void *> (&scan_starts_kernel<SYM, true, false>);
   return count_only ? reinterpret_cast<const void *> (&scan_starts_kernel<SYM, false, true>)
                     : reinterpret_cast<const void *> (&scan_starts_kernel<SYM, false, false>);
+}
+
+const void *
+short_kernel_ptr (bool count_only, bool ids_lds) {
+  if (count_only)
+    return reinterpret_cast<const void *> (&scan_short_kernel<true, true>);
+  return ids_lds ? reinterpret_cast<const void *> (&scan_short_kernel<false, true>) : reinterpret_cast<const void *> (&scan_short_kernel<false, false>);
 }
 
 const void *
@@ -806,6 +816,15 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
   const size_t o_g4bits = blob_reserve (cur, gram ? (size_t)(bloom5_bits ? bloom_off + bloom_bytes : g3_off + g3_bytes) + 16 : 0);
   const size_t o_g3rec = blob_reserve (cur, gram_shorts && !gram_wide ? (size_t)gW3 * 16 : 0);
   const size_t o_stab = blob_reserve (cur, gram_wide && gram_shorts ? ((size_t)8 << stab_log2) : 0);
+  /* scan_short_kernel's LDS image: the nibbles, the number of set nibble bits in front of every 8
+   * 3-grams, the keyword ids in the order of those bits (a keyword of d symbols is the id of W^(3-d) 3-grams) */
+  uint32_t sh_ids = 0;
+  for (uint32_t st = 1; gram_shorts && !gram_wide && st < fv.depth_start[4 <= fi.lmax + 1 ? 4 : fi.lmax + 1]; st++)
+    if (fv.term_kw[st] != NONE)
+      sh_ids += fv.depth[st] == 1 ? gW * gW : (fv.depth[st] == 2 ? gW : 1u);
+  const uint32_t sh_nib_bytes = g3_bytes, sh_base_bytes = gram_shorts && !gram_wide ? (((gW3 + 7) / 8) * 4 + 15) & ~15u : 0;
+  const uint32_t sh_ids_bytes = (sh_ids * 4 + 15) & ~15u;
+  const size_t o_shimg = blob_reserve (cur, gram_shorts && !gram_wide ? (size_t)sh_nib_bytes + sh_base_bytes + sh_ids_bytes + 16 : 0);
   const size_t o_g4rec = blob_reserve (cur, gram ? (size_t)gW4 * 8 : 0);
   const size_t o_grec = blob_reserve (cur, gram ? (size_t)n * 32 : 0);
   const size_t o_gedge = blob_reserve (cur, gram ? (size_t)fi.n_edges * 8 : 0);
@@ -879,6 +898,24 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     G.rows2 = rows2 ? reinterpret_cast<uint32_t *> (&host[o_rows2]) : nullptr;
     G.over2 = rows2 ? reinterpret_cast<uint32_t *> (&host[o_over2]) : nullptr;
     fill_gram_tables (fv, fi, G);
+    if (gram_shorts && !gram_wide) {
+      unsigned char *img = &host[o_shimg];
+      memcpy (img, G.nib, (gW3 + 1) / 2);
+      uint32_t *base = reinterpret_cast<uint32_t *> (img + sh_nib_bytes), *ids = reinterpret_cast<uint32_t *> (img + sh_nib_bytes + sh_base_bytes);
+      uint32_t r = 0;
+      for (uint32_t i3 = 0; i3 < gW3; i3++) {
+        if ((i3 & 7) == 0)
+          base[i3 >> 3] = r;
+        const uint32_t nb = (G.nib[i3 >> 1] >> ((i3 & 1) * 4)) & 7u;
+        for (uint32_t d = 0; d < 3; d++)
+          if ((nb >> d) & 1u)
+            ids[r++] = G.g3[4 * (size_t)i3 + d];
+      }
+      if (r != sh_ids) { /* (the two counts are of the same keywords) */
+        delete p;
+        return ACM_GPU_E_ARG;
+      }
+    }
   }
   if (dense) {
     int rc = acm_flat_dense_rows (flat, n, entry_bytes, &host[o_dense]);
@@ -1013,7 +1050,18 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
       p->GK.short_lens = short_lens;
       p->gram_shorts = gram_shorts && gram_wide; /* (the kernel's own short-keyword path: hashed windows only) */
       p->short_pass = gram_shorts && !gram_wide;
-      p->short_lds_bytes = ((g3_bytes + 15) & ~15u) + SH_LDS_FIXED;
+      p->GK.sh_img = u32p (o_shimg);
+      p->GK.sh_nib_bytes = sh_nib_bytes;
+      p->GK.sh_base_bytes = sh_base_bytes;
+      p->GK.sh_ids_bytes = sh_ids_bytes;
+      /* the ids in LDS too while they fit (29 K of them beside the tables and the waves' areas) */
+      p->short_ids_lds = (uint64_t)sh_nib_bytes + sh_base_bytes + sh_ids_bytes + SH_LDS_FIXED <= lds_total;
+      p->short_lds_bytes = sh_nib_bytes + sh_base_bytes + (p->short_ids_lds ? sh_ids_bytes : 0u) + SH_LDS_FIXED;
+      p->short_lds_count_bytes = sh_nib_bytes + SH_LDS_FIXED;
+      p->short_blocks_per_cu = 2u * (sh_nib_bytes + SH_LDS_FIXED) <= 160u * 1024u ? 2u : 1u; /* (count-only: the nibbles alone) */
+      if (const char *e = getenv ("ACM_GPU_SHORT_BLOCKS"))
+        if (atoi (e) == 1)
+          p->short_blocks_per_cu = 1;
       p->gram_wide = gram_wide;
       p->GK.W = gW;
       p->GK.lo = fi.alpha_lo;
@@ -1164,6 +1212,10 @@ plan_create_flat_kw (const ACMFlat *flat, int device, uint32_t kw_base, ACMPlan 
     if (!p->gram_wide)
       PLAN_TRY (hipFuncSetAttribute (gram_kernel_ptr (false, p->gram_shorts, false, true, p->gram2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)p->gram_lds_bytes));
+    if (p->short_pass)
+      for (int co = 0; co < 2; co++)
+        PLAN_TRY (hipFuncSetAttribute (short_kernel_ptr (co != 0, p->short_ids_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(co ? p->short_lds_count_bytes : p->short_lds_bytes)));
   }
   if (dense && !p->gram) {
     for (int co = 0; co < 2; co++)
@@ -1318,7 +1370,7 @@ acm_gpu_plan_info (const ACMPlan *plan, ACMPlanInfo *info) {
   info->delta_keywords = plan->delta ? plan->delta->finfo.n_keywords : 0;
   info->merges = plan->merges;
   info->records_direct = ((plan->gram && !plan->gram_wide) || plan->info.kernel == 2) ? 1u : 0u;
-  info->variant = (plan->gram2 ? 2u : 0u) | (plan->short_pass ? 4u : 0u);
+  info->variant = (plan->gram2 ? 2u : 0u) | (plan->short_pass ? 4u : 0u) | (plan->short_pass && !plan->short_ids_lds ? 8u : 0u);
 }
 
 extern "C" int
@@ -1580,14 +1632,16 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t 
 template <bool COUNT_ONLY>
 int
 launch_short (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop, bool first_segment, bool last_segment) {
-  uint32_t grid = (uint32_t)p->cu_count;
+  /* (count-only: 61 registers, two blocks a CU while LDS allows; with records one) */
+  uint32_t grid = (uint32_t)p->cu_count * (COUNT_ONLY ? p->short_blocks_per_cu : 1u);
   const uint32_t wpb = SPARSE_THREADS / WAVE;
+  const uint32_t short_regions = p->direct_regions;
   /* a match of 1-3 symbols that ends at emit_from or later starts no earlier than emit_from - 2 */
   const uint32_t group = WAVE * 16;
   const uint32_t ngroups = (uint32_t)(((uint64_t)a.n + group - 1) / group);
   const uint32_t first_group = (a.emit_from > 2 ? a.emit_from - 2 : 0) / group;
   uint64_t R = (ngroups - first_group) / ((uint64_t)grid * wpb * 16);
-  R = R < GRAM_R_MIN ? GRAM_R_MIN : (R > 64 ? 64 : R);
+  R = R < 4 ? 4 : (R > 64 ? 64 : R & ~3ull); /* (a multiple of 4: the kernel takes a tile's groups four at a time) */
   GramK K = p->GK;
   K.R = (uint32_t)R;
   a.range_begin = first_group / (uint32_t)R;
@@ -1599,14 +1653,14 @@ launch_short (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
   RecHole *holes = COUNT_ONLY ? nullptr : static_cast<RecHole *> (p->d_holes) + p->direct_regions;
   uint32_t resume = first_segment ? 0u : 1u;
   if (holes && first_segment)
-    HIP_TRY (hipMemsetAsync (holes, 0, (size_t)p->direct_regions * sizeof (RecHole), st));
+    HIP_TRY (hipMemsetAsync (holes, 0, (size_t)short_regions * sizeof (RecHole), st));
   void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &holes, &resume };
-  HIP_TRY (hipLaunchKernel (COUNT_ONLY ? reinterpret_cast<const void *> (&scan_short_kernel<true>) : reinterpret_cast<const void *> (&scan_short_kernel<false>),
-                            dim3 (grid), dim3 (SPARSE_THREADS), args, p->short_lds_bytes, st));
+  HIP_TRY (hipLaunchKernel (short_kernel_ptr (COUNT_ONLY, p->short_ids_lds), dim3 (grid), dim3 (SPARSE_THREADS), args,
+                            COUNT_ONLY ? p->short_lds_count_bytes : p->short_lds_bytes, st));
   if (stop)
     HIP_TRY (hipEventRecord (stop, st));
   if (!COUNT_ONLY && last_segment) {
-    const uint32_t n_waves = p->direct_regions;
+    const uint32_t n_waves = short_regions;
     uint32_t npow = 64;
     while (npow < n_waves)
       npow <<= 1;
@@ -1699,9 +1753,9 @@ ensure_item_buffer (ACMPlan *user, uint64_t n, uint32_t symbols_per_item = 256, 
  * items, smaller blocks and fewer rounds: DESIGN.md 4.2) */
 /* hole descriptors and spill area of a plan whose scan kernel writes the records itself */
 int
-ensure_direct_buffers (ACMPlan *p) {
+ensure_direct_buffers (ACMPlan *p, uint32_t rec_chunk) {
   const uint32_t regions = (uint32_t)p->cu_count * (SPARSE_THREADS / WAVE);
-  if (p->d_holes && p->d_spill && p->direct_regions >= regions)
+  if (p->d_holes && p->d_spill && p->direct_regions >= regions && p->spill_chunk >= rec_chunk)
     return ACM_GPU_OK;
   if (p->d_holes || p->d_spill)
     HIP_TRY (hipDeviceSynchronize ());
@@ -1711,9 +1765,10 @@ ensure_direct_buffers (ACMPlan *p) {
     HIP_TRY (hipFree (p->d_spill));
   p->d_holes = p->d_spill = nullptr;
   if (hipMalloc (&p->d_holes, (size_t)regions * 2 * sizeof (RecHole)) != hipSuccess || /* (the 4-gram pass's and the short-keyword pass's) */
-      hipMalloc (&p->d_spill, (size_t)regions * REC_CHUNK * 16) != hipSuccess)
+      hipMalloc (&p->d_spill, (size_t)regions * rec_chunk * 16) != hipSuccess) /* (one chunk per wave: 64 MB, 256 MB with big chunks) */
     return ACM_GPU_E_NOMEM;
   p->direct_regions = regions;
+  p->spill_chunk = rec_chunk;
   return ACM_GPU_OK;
 }
 
@@ -2200,15 +2255,21 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
     if (rc)
       return rc;
   }
+  const bool tiled = !COUNT_ONLY && direct && p->tiled_dir != nullptr;
+  /* slots per chunk of records (EmitCtx::rec_chunk): big chunks for long texts, when no directory
+   * of tiles counts in chunks (ACM_GPU_REC_CHUNK=1024 / 4096: one or the other anyway -- tests) */
+  uint32_t rec_chunk = (!tiled && n >= (64ull << 20)) ? REC_CHUNK_BIG : REC_CHUNK;
+  if (const char *e = getenv ("ACM_GPU_REC_CHUNK"))
+    if (!tiled && (atoi (e) == (int)REC_CHUNK || atoi (e) == (int)REC_CHUNK_BIG))
+      rec_chunk = (uint32_t)atoi (e);
   if (!COUNT_ONLY && direct) {
-    int rc = ensure_direct_buffers (p);
+    int rc = ensure_direct_buffers (p, rec_chunk);
     if (rc)
       return rc;
   }
   EmitCtx E{};
   E.oinfo = p->d_oinfo;
   E.records = d_records;
-  const bool tiled = !COUNT_ONLY && direct && p->tiled_dir != nullptr;
   E.count = shared_total ? shared_total : ((use_dense || accumulate || tiled) ? p->d_total : reinterpret_cast<unsigned long long *> (d_count));
   E.capacity = COUNT_ONLY ? 0 : capacity;
   E.wrows = p->d_wrows;
@@ -2222,7 +2283,8 @@ scan_impl (ACMPlan *p, const void *d_text, uint64_t n, uint64_t emit_from, uint6
   E.chain = p->d_chain;
   E.chain_base = p->K.HD;
   E.spill = static_cast<uint4 *> (p->d_spill);
-  E.spill_slots = (!COUNT_ONLY && direct && !tiled) ? (uint64_t)p->direct_regions * REC_CHUNK : 0;
+  E.spill_slots = (!COUNT_ONLY && direct && !tiled) ? (uint64_t)p->direct_regions * rec_chunk : 0;
+  E.rec_chunk = rec_chunk;
   E.chunk_prev = tiled ? p->tiled_prev : nullptr;
   E.error = p->d_total ? reinterpret_cast<unsigned int *> (p->d_total) + 3 : nullptr;
 

@@ -89,6 +89,11 @@ struct EmitCtx {
   /* tiled scans (dev_tiles.h): `records` is a raw area of whole chunks, and a wave that reserves
    * chunk c writes chunk_prev[c] = the chunk it filled before (NONE: its first) */
   uint32_t *chunk_prev;
+  /* slots per chunk of records a wave reserves with one atomic on the record counter: REC_CHUNK in
+   * tiled scans (their directory counts in chunks of that size), REC_CHUNK_BIG in other scans of
+   * long texts -- every wave of the chip adds to the same counter, 4.8 ns a time: a dictionary of
+   * short keywords (164 M records from 2 GiB) spent 0.78 of 1.98 ms on 161 K reservations */
+  uint32_t rec_chunk;
 };
 constexpr uint32_t HIT_LEN4 = 0x80000000u;
 /* the hit's word is the keyword itself: id (below 2^28) | length << 28 (1-3; 0: 4 symbols) | HIT_KW -- what

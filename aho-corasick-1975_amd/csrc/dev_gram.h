@@ -38,6 +38,10 @@ struct GramK {
    * symbols are a keyword) and a record {state of the 1-, 2-, 3-symbol prefix, -} in HBM */
   const uint4 *g3rec;
   uint32_t g3_off, g3_bytes; /* nibble table in LDS, right after the 4-gram bits; 0 bytes: no short keywords */
+  /* scan_short_kernel's image (dev_short.h): the nibbles, per 8 3-grams the number of set nibble
+   * bits in front of them, the keyword ids in the order of those bits */
+  const uint32_t *sh_img;
+  uint32_t sh_nib_bytes, sh_base_bytes, sh_ids_bytes;
   /* wide alphabets (template WIDE): g4bits is a Bloom filter of 2^bloom_log2 bits on the hashed
    * 4-byte window, wtab an open-addressing table {window, depth-4 state | has children << 30 |
    * terminal << 31} of 2^wtab_log2 slots (state 0: empty slot) */
@@ -208,17 +212,17 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       const RecHole h = holes[wave_id];
       if (h.len) {
         const unsigned long long at = ((unsigned long long)h.start_hi << 32) | h.start_lo; /* first free slot */
-        const unsigned long long base = at + h.len - REC_CHUNK;
-        const bool below = base + REC_CHUNK <= E.capacity;
-        const bool above = base >= E.capacity && base - E.capacity + REC_CHUNK <= E.spill_slots;
+        const unsigned long long base = at + h.len - E.rec_chunk;
+        const bool below = base + E.rec_chunk <= E.capacity;
+        const bool above = base >= E.capacity && base - E.capacity + E.rec_chunk <= E.spill_slots;
         const uint64_t dst = below ? reinterpret_cast<uint64_t> (&E.records[base]) : (above ? reinterpret_cast<uint64_t> (E.spill + (base - E.capacity)) : 0ull);
         w0.dst_lo = (uint32_t)dst;
         w0.dst_hi = (uint32_t)(dst >> 32);
         w0.base_lo = (uint32_t)base;
         w0.base_hi = (uint32_t)(base >> 32);
-        w0.limit = (below || above) ? REC_CHUNK : 0u;
+        w0.limit = (below || above) ? E.rec_chunk : 0u;
         w0.have = 1;
-        w0.pad[0] = REC_CHUNK - h.len; /* slots used */
+        w0.pad[0] = E.rec_chunk - h.len; /* slots used */
         w0.pad[1] = 1;
         w0.prev1 = w0.prev2 = NONE;
       }
@@ -730,7 +734,7 @@ scan_gram_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict_
       if (lane == 0 && holes) {
         const WaveRec w = Ws[wib];
         const unsigned long long at = (((unsigned long long)w.base_hi << 32) | w.base_lo) + (uint32_t)counted;
-        RecHole h = { (uint32_t)at, (uint32_t)(at >> 32), w.have ? REC_CHUNK - (uint32_t)counted : 0u, 0u };
+        RecHole h = { (uint32_t)at, (uint32_t)(at >> 32), w.have ? E.rec_chunk - (uint32_t)counted : 0u, 0u };
         holes[wave_id] = h;
       }
     } else {

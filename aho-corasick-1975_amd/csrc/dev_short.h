@@ -16,30 +16,48 @@
  *   - a lane looks its 16 positions' nibbles up and keeps "something ends here" as bits of one
  *     register; a wave-wide prefix sum per group, the survivors' positions listed in LDS, batches of
  *     64 put together in registers across groups (the sieve of scan_gram2_kernel, dev_gram2.h);
- *   - a batch asks for the keyword ids of its 3-grams' three prefixes (GramK::g3rec: 16 bytes from
- *     W^3 entries, 315 KB for a-z) and writes the records a step later, straight into the wave's
- *     chunk of the caller's buffer (dev_starts.h: WaveRec, emit_terminals); the holes its waves
- *     leave are closed behind its last segment (close_holes_kernel, a second set of descriptors). */
+ *   - the keyword ids by RANK, from LDS: the number of set nibble bits in front of every 8 3-grams
+ *     + the set bits of the word in front of the 3-gram's = where its ids are in a table that has
+ *     one entry per set bit (a few KB; a keyword of d symbols is the id of W^(3-d) 3-grams).  No
+ *     load from memory but the text: the first version asked HBM for 16 bytes per surviving
+ *     position (W^3 entries) a batch ahead, and every wait for those was a wait for the text
+ *     prefetched behind them too (vmcnt counts in order) -- 2.0 ms per 2 GiB against 1.07 ms
+ *     count-only, and neither the lines asked for nor the stores were what it cost
+ *     (tools/ablate_short.sh).  Dictionaries whose ids do not fit LDS read them from the image in
+ *     HBM (IDS_LDS = false);
+ *   - records: one reservation per batch (a prefix sum over the lanes' 0-3 records), written
+ *     straight into the wave's chunk of the caller's buffer (dev_starts.h: WaveRec); the holes the
+ *     waves leave are closed behind the last segment (close_holes_kernel, a second set of descriptors);
+ *   - the text: four register sets that swap roles over four groups (a tile is a multiple of four
+ *     groups), no copies between them -- a copy of the newest set at the top of every group had
+ *     made the top wait for the load issued one group before. */
 constexpr uint32_t SH_STAGE = WAVE * 16 + 16, SH_LIST = 256; /* staged text of a group + 8 bytes behind it; survivor positions per round */
 constexpr uint32_t SH_WAVE_BYTES = SH_STAGE + SH_LIST * 2;
 static_assert (SH_WAVE_BYTES % 16 == 0, "the staged text is written 16 bytes per lane");
 constexpr uint32_t SH_CTX_BYTES = 16 + WALK_CTX_E + (SPARSE_THREADS / WAVE) * sizeof (WaveRec);
-constexpr uint32_t SH_LDS_FIXED = (SPARSE_THREADS / WAVE) * SH_WAVE_BYTES + SH_CTX_BYTES; /* + the nibbles */
+constexpr uint32_t SH_LDS_FIXED = (SPARSE_THREADS / WAVE) * SH_WAVE_BYTES + SH_CTX_BYTES; /* + the image */
 
-template <bool COUNT_ONLY>
-__global__ __launch_bounds__ (SPARSE_THREADS) void
+/* count-only: 61 registers, two blocks a CU; with records one block (a spilled register's reload
+ * sat right behind the prefetch and waited for it) */
+#ifndef SH_OCCUPANCY
+#define SH_OCCUPANCY __attribute__ ((amdgpu_waves_per_eu (COUNT_ONLY ? 8 : 4, 8)))
+#endif
+template <bool COUNT_ONLY, bool IDS_LDS>
+__global__ __launch_bounds__ (SPARSE_THREADS) SH_OCCUPANCY void
 scan_short_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict__ text, RecHole *holes, uint32_t resume) {
   extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
   constexpr uint32_t WAVES = SPARSE_THREADS / WAVE;
   constexpr uint32_t GROUP = WAVE * 16;
-  const uint32_t nib_bytes = (K.g3_bytes + 15) & ~15u;
+  /* LDS: nibbles | (records) bases | (records, IDS_LDS) ids | the waves' areas | context */
+  const uint32_t base_off = K.sh_nib_bytes, ids_off = base_off + K.sh_base_bytes;
+  const uint32_t image = COUNT_ONLY ? K.sh_nib_bytes : ids_off + (IDS_LDS ? K.sh_ids_bytes : 0u);
   {
     uint4 *dst = reinterpret_cast<uint4 *> (smem);
-    const uint4 *src = reinterpret_cast<const uint4 *> (reinterpret_cast<const unsigned char *> (K.g4bits) + K.g3_off);
-    for (uint32_t i = threadIdx.x; i < nib_bytes / 16; i += blockDim.x)
+    const uint4 *src = reinterpret_cast<const uint4 *> (K.sh_img);
+    for (uint32_t i = threadIdx.x; i < image / 16; i += blockDim.x)
       dst[i] = src[i];
   }
-  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + nib_bytes + WAVES * SH_WAVE_BYTES);
+  uint32_t *next_tile = reinterpret_cast<uint32_t *> (smem + image + WAVES * SH_WAVE_BYTES);
   EmitCtx *Es = reinterpret_cast<EmitCtx *> (next_tile + 4);
   WaveRec *Ws = reinterpret_cast<WaveRec *> (reinterpret_cast<unsigned char *> (Es) + WALK_CTX_E);
   if (threadIdx.x == 0) {
@@ -49,7 +67,7 @@ scan_short_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
   __syncthreads ();
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint32_t wib = uniform (threadIdx.x / WAVE);
-  const uint32_t stage_off = nib_bytes + wib * SH_WAVE_BYTES, list_off = stage_off + SH_STAGE;
+  const uint32_t stage_off = image + wib * SH_WAVE_BYTES, list_off = stage_off + SH_STAGE;
   const uint32_t wave_id = blockIdx.x * WAVES + wib;
   uint2 *hits = reinterpret_cast<uint2 *> (Ws + wib);
   if (lane == 0) {
@@ -59,17 +77,17 @@ scan_short_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
       const RecHole h = holes[wave_id];
       if (h.len) {
         const unsigned long long at = ((unsigned long long)h.start_hi << 32) | h.start_lo;
-        const unsigned long long base = at + h.len - REC_CHUNK;
-        const bool below = base + REC_CHUNK <= E.capacity;
-        const bool above = base >= E.capacity && base - E.capacity + REC_CHUNK <= E.spill_slots;
+        const unsigned long long base = at + h.len - E.rec_chunk;
+        const bool below = base + E.rec_chunk <= E.capacity;
+        const bool above = base >= E.capacity && base - E.capacity + E.rec_chunk <= E.spill_slots;
         const uint64_t dst = below ? reinterpret_cast<uint64_t> (&E.records[base]) : (above ? reinterpret_cast<uint64_t> (E.spill + (base - E.capacity)) : 0ull);
         w0.dst_lo = (uint32_t)dst;
         w0.dst_hi = (uint32_t)(dst >> 32);
         w0.base_lo = (uint32_t)base;
         w0.base_hi = (uint32_t)(base >> 32);
-        w0.limit = (below || above) ? REC_CHUNK : 0u;
+        w0.limit = (below || above) ? E.rec_chunk : 0u;
         w0.have = 1;
-        w0.pad[0] = REC_CHUNK - h.len;
+        w0.pad[0] = E.rec_chunk - h.len;
         w0.pad[1] = 1;
         w0.prev1 = w0.prev2 = NONE;
       }
@@ -92,86 +110,94 @@ scan_short_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
   auto lds_word = [&] (uint32_t byte_off) -> uint32_t {
     return *reinterpret_cast<const __attribute__ ((address_space (3))) uint32_t *> (byte_off);
   };
-  auto nibble = [&] (uint32_t idx3) -> uint32_t { /* bit d - 1: the first d symbols of the 3-gram are a keyword */
-    const uint32_t b = *reinterpret_cast<const __attribute__ ((address_space (3))) unsigned char *> (idx3 >> 1);
-    return (b >> ((idx3 & 1u) * 4u)) & 7u;
-  };
   auto load_group = [&] (uint32_t g) -> uint4 {
     const uint32_t blk = g * WAVE + lane;
     const u32x4 v = __builtin_nontemporal_load (reinterpret_cast<const u32x4 *> (text16) + (blk < last_blk ? blk : last_blk));
     return make_uint4 (v.x, v.y, v.z, v.w);
   };
-  /* the batch that is being put together: lanes [0, pk) hold (position, 3-gram index | nibble << 20);
-   * the batch whose ids are in flight */
+  auto id_at = [&] (uint32_t rank) -> uint32_t {
+    if (IDS_LDS)
+      return lds_word (ids_off + rank * 4u);
+    return K.sh_img[(ids_off >> 2) + rank];
+  };
+  /* the batch that is being put together: lanes [0, pk) hold (position, rank of the 3-gram's first id | nibble << 20) */
   uint32_t it_x = 0, it_y = 0, pk = 0;
-  uint2 pend_item = make_uint2 (0, 0);
-  uint32_t pend_k1 = 0, pend_k2 = 0, pend_k3 = 0, pend_n = 0; /* (words, not a uint4 temporary) */
-  auto consume_pending = [&] () {
-    if (pend_n == 0)
-      return;
-    uint32_t nib = lane < pend_n ? pend_item.y >> 20 : 0u;
+  /* a batch's records: bit d - 1 of a lane's nibble = "the keyword of d symbols that starts here",
+   * its id the (set bits below it)th behind the lane's rank */
+  auto emit_batch = [&] (uint32_t n_items) {
+    const uint32_t nib0 = lane < n_items ? it_y >> 20 : 0u;
+    uint32_t nib = nib0;
     /* (a keyword of d symbols that starts at position p ends at p + d - 1: not before emit_from) */
-    if (pend_item.x < E.emit_from)
-      nib &= pend_item.x + 1 >= E.emit_from ? 6u : (pend_item.x + 2 >= E.emit_from ? 4u : 0u);
+    if (it_x < E.emit_from)
+      nib &= it_x + 1 >= E.emit_from ? 6u : (it_x + 2 >= E.emit_from ? 4u : 0u);
     const uint32_t mine = __popc (nib);
     if (COUNT_ONLY) {
       counted += mine;
-      pend_n = 0;
       return;
     }
-    /* the batch's records in ONE reservation: every lane's up to three side by side (a prefix sum
-     * over the lanes' counts; a ballot and a rank per length were three of each per batch) */
     const uint32_t incl = wave_incl_scan_dpp (mine);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane ((int)incl, WAVE - 1);
+    if (total == 0)
+      return;
+#if defined(ACM_SHORT_ABLATE) && ACM_SHORT_ABLATE == 3 /* experiment: the batch's records are counted across the wave, nothing else */
+    asm volatile ("" :: "v"(incl), "v"(it_y));
+    return;
+#endif
+    const uint32_t rank = it_y & 0xFFFFFu;
+    const uint32_t r1 = rank + (nib0 & 1u), r2 = r1 + ((nib0 >> 1) & 1u);
+    uint32_t k1 = 0, k2 = 0, k3 = 0;
+#if defined(ACM_SHORT_ABLATE) && ACM_SHORT_ABLATE == 4 /* experiment: the ranks instead of the ids */
+    k1 = rank, k2 = r1, k3 = r2;
+#else
+    if (nib & 1u)
+      k1 = id_at (rank);
+    if (nib & 2u)
+      k2 = id_at (r1);
+    if (nib & 4u)
+      k3 = id_at (r2);
+#endif
     const uint32_t used = (uint32_t)counted;
-    if (total && used + total <= rs.limit) {
+    if (used + total <= rs.limit) {
+      /* ONE reservation: every lane's up to three records side by side */
       typedef uint32_t g_u32x4 __attribute__ ((ext_vector_type (4)));
       uint64_t at = rs.dst + ((uint64_t)(used + incl - mine) << 4);
 #pragma unroll
       for (uint32_t d = 0; d < 3; d++) {
         if ((nib >> d) & 1u) {
-          const uint64_t gp = E.pos_base + pend_item.x + d;
+          const uint64_t gp = E.pos_base + it_x + d;
+#if defined(ACM_SHORT_ABLATE) && ACM_SHORT_ABLATE == 2 /* experiment: the records are put together, not written */
+          asm volatile ("" :: "v"(gp), "v"(k1), "v"(k2), "v"(k3), "v"(at));
+          continue;
+#endif
           *reinterpret_cast<__attribute__ ((address_space (1))) g_u32x4 *> (at) =
-            g_u32x4{ (uint32_t)gp, (uint32_t)(gp >> 32), d + 1, d == 0 ? pend_k1 : (d == 1 ? pend_k2 : pend_k3) };
+            g_u32x4{ (uint32_t)gp, (uint32_t)(gp >> 32), d + 1, d == 0 ? k1 : (d == 1 ? k2 : k3) };
           at += 16;
         }
       }
       counted = used + total;
-    } else if (total) {
+    } else {
       /* (the chunk ends inside the batch, or there is none yet: length by length through the path that reserves the next) */
 #pragma unroll
       for (uint32_t d = 0; d < 3; d++) {
-        emit_terminals<COUNT_ONLY, true> (E, ((nib >> d) & 1u) != 0, pend_item.x + d, d == 0 ? pend_k1 : (d == 1 ? pend_k2 : pend_k3), d + 1, lane, hits, counted, Es, &rs);
+        emit_terminals<COUNT_ONLY, true> (E, ((nib >> d) & 1u) != 0, it_x + d, d == 0 ? k1 : (d == 1 ? k2 : k3), d + 1, lane, hits, counted, Es, &rs);
         counted = uniform ((uint32_t)counted);
       }
     }
-    pend_n = 0;
-  };
-  auto batch_step = [&] (uint32_t n_items) {
-    consume_pending ();
-    uint4 ids = make_uint4 (0, 0, 0, 0);
-    if (!COUNT_ONLY && lane < n_items)
-      ids = K.g3rec[it_y & 0xFFFFFu];
-    pend_k1 = ids.x;
-    pend_k2 = ids.y;
-    pend_k3 = ids.z;
-    pend_item = make_uint2 (it_x, it_y);
-    pend_n = n_items;
   };
   auto drain = [&] () {
     if (pk) {
-      batch_step (pk);
+      emit_batch (pk);
       pk = 0;
     }
-    consume_pending ();
   };
-  /* one group: cur = this lane's 16 bytes, (next_x, next_y) = the first 8 bytes of every lane of the next group */
+  /* one group: cur = this lane's 16 bytes, (next_x, next_y) = the first 8 bytes of every lane of the
+   * next group; `prefetched` takes the group three ahead (a register set of its own) */
   auto walk_group = [&] (const uint4 cur, const uint32_t next_x, const uint32_t next_y, const uint32_t g, uint4 &prefetched) {
     uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp ((int)uniform (next_x), (int)cur.x, 0x130, 0xf, 0xf, false); /* word 0 of the next lane */
     const uint32_t t5 = (uint32_t)__builtin_amdgcn_update_dpp ((int)uniform (next_y), (int)cur.y, 0x130, 0xf, 0xf, false);
     asm volatile ("" : "+v"(t4));
     __builtin_amdgcn_sched_barrier (0);
-    prefetched = load_group (g + 4);
+    prefetched = load_group (g + 3);
     *reinterpret_cast<__attribute__ ((address_space (3))) u32x4 *> (stage_off + lane * 16u) = u32x4{ cur.x, cur.y, cur.z, cur.w };
     if (lane == WAVE - 1)
       *reinterpret_cast<__attribute__ ((address_space (3))) u32x2 *> (stage_off + GROUP) = u32x2{ t4, t5 };
@@ -190,16 +216,22 @@ scan_short_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
         if (pos0 + j >= A.n)
           c[j] = K.span;
     }
-    uint32_t pass = 0, ix[16], nb[16];
+    uint32_t pass = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      ix[j] = __umul24 (__umul24 (c[j], K.W) + c[j + 1], K.W) + c[j + 2];
-      nb[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) unsigned char *> (ix[j] >> 1);
-    }
+    for (int h = 0; h < 16; h += 8) { /* (two rounds of eight reads: the indices and bytes of sixteen were 32 registers) */
+      uint32_t ix[8], nb[8];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint32_t nib = (nb[j] >> ((ix[j] & 1u) * 4u)) & 7u;
-      pass |= min (nib, 1u) << j;
+      for (int j = 0; j < 8; j++) {
+        ix[j] = __umul24 (__umul24 (c[h + j], K.W) + c[h + j + 1], K.W) + c[h + j + 2];
+        nb[j] = *reinterpret_cast<const __attribute__ ((address_space (3))) unsigned char *> (ix[j] >> 1);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t nib = (nb[j] >> ((ix[j] & 1u) * 4u)) & 7u;
+        pass |= min (nib, 1u) << (h + j);
+      }
+      if (h == 0)
+        __builtin_amdgcn_sched_barrier (0);
     }
     if (pos0 + 16 > A.n) /* (a position beyond the segment is no position) */
       pass &= pos0 < A.n ? (1u << (A.n - pos0)) - 1u : 0u;
@@ -243,13 +275,18 @@ scan_short_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
               r[k] = K.span;
         }
         const uint32_t idx3 = __umul24 (__umul24 (r[0], K.W) + r[1], K.W) + r[2];
-        const uint32_t y = idx3 | nibble (idx3) << 20;
+        /* the nibbles of the 8 3-grams around it (one word): its own, and how many set bits lie in front of it */
+        const uint32_t word = lds_word ((idx3 >> 3) * 4u) & 0x77777777u;
+        const uint32_t sh = (idx3 & 7u) * 4u;
+        uint32_t y = ((word >> sh) & 7u) << 20;
+        if (!COUNT_ONLY)
+          y |= lds_word (base_off + (idx3 >> 3) * 4u) + __popc (word & ((1u << sh) - 1u));
         it_x = mine ? p : it_x;
         it_y = mine ? y : it_y;
         pk += take;
         off += take;
         if (pk == WAVE) {
-          batch_step (WAVE);
+          emit_batch (WAVE);
           pk = 0;
         }
       }
@@ -260,14 +297,18 @@ scan_short_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
     if (tile == NONE)
       break;
     const uint32_t g0 = tile * K.R;
-    uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
-    for (uint32_t k = 0; k < K.R; k++) {
-      uint4 n3;
-      walk_group (c0, c1.x, c1.y, g0 + k, n3);
-      c0 = c1;
-      c1 = c2;
-      c2 = c3;
-      c3 = n3;
+    /* (asked for in this order: the top of the loop waits for "all but the newest", whichever way it is entered) */
+    uint4 c0 = load_group (g0), c3;
+    __builtin_amdgcn_sched_barrier (0);
+    uint4 c1 = load_group (g0 + 1);
+    __builtin_amdgcn_sched_barrier (0);
+    uint4 c2 = load_group (g0 + 2);
+    __builtin_amdgcn_sched_barrier (0);
+    for (uint32_t k = 0; k < K.R; k += 4) { /* (K.R is a multiple of 4) */
+      walk_group (c0, c1.x, c1.y, g0 + k, c3);
+      walk_group (c1, c2.x, c2.y, g0 + k + 1, c0);
+      walk_group (c2, c3.x, c3.y, g0 + k + 2, c1);
+      walk_group (c3, c0.x, c0.y, g0 + k + 3, c2);
     }
   }
   drain ();
@@ -280,7 +321,7 @@ scan_short_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
     /* what is left of the wave's last chunk is a hole for close_holes_kernel */
     const WaveRec w = Ws[wib];
     const unsigned long long at = (((unsigned long long)w.base_hi << 32) | w.base_lo) + (uint32_t)counted;
-    RecHole h = { (uint32_t)at, (uint32_t)(at >> 32), w.have ? REC_CHUNK - (uint32_t)counted : 0u, 0u };
+    RecHole h = { (uint32_t)at, (uint32_t)(at >> 32), w.have ? E.rec_chunk - (uint32_t)counted : 0u, 0u };
     holes[wave_id] = h;
   }
 }

@@ -204,9 +204,9 @@ expand_hits_kernel (EmitCtx E, const uint2 *items, uint32_t region_items, uint32
 #ifndef ACM_REC_CHUNK
 #define ACM_REC_CHUNK 1024
 #endif
-constexpr uint32_t REC_CHUNK = ACM_REC_CHUNK;
+constexpr uint32_t REC_CHUNK = ACM_REC_CHUNK, REC_CHUNK_BIG = 4096;
 constexpr uint32_t HOLE_BITS = 13; /* close_holes_kernel's sort keys: first slot << HOLE_BITS | length */
-static_assert (REC_CHUNK < (1u << HOLE_BITS) && REC_CHUNK % 1024 == 0, "a hole's length fits its key");
+static_assert (REC_CHUNK <= REC_CHUNK_BIG && REC_CHUNK_BIG < (1u << HOLE_BITS) && REC_CHUNK % 1024 == 0, "a hole's length fits its key");
 struct WaveRec {
   uint32_t dst_lo, dst_hi;   /* address of slot 0 of the current chunk (meaningless while limit == 0) */
   uint32_t base_lo, base_hi; /* index of that slot */
@@ -257,7 +257,8 @@ emit_records_slow (const EmitCtx *Ep, WaveRec *W, uint32_t used, bool hit, uint3
   const uint32_t total = (uint32_t)__popcll (m), rank = rank_below (m);
   const uint32_t lane = lane_id ();
   unsigned long long base = ((unsigned long long)W->base_hi << 32) | W->base_lo;
-  const uint32_t room = W->have ? REC_CHUNK - used : 0u;
+  const uint32_t chunk = E.rec_chunk;
+  const uint32_t room = W->have ? chunk - used : 0u;
   const uint64_t gp = E.pos_base + p;
   const uint4 rec = make_uint4 ((uint32_t)gp, (uint32_t)(gp >> 32), length, kw);
   if (hit && rank < room) {
@@ -270,7 +271,7 @@ emit_records_slow (const EmitCtx *Ep, WaveRec *W, uint32_t used, bool hit, uint3
   /* next chunk: one atomic for the wave */
   unsigned long long nb = 0;
   if (lane == 0)
-    nb = atomicAdd (E.count, (unsigned long long)REC_CHUNK);
+    nb = atomicAdd (E.count, (unsigned long long)chunk);
   nb = ((unsigned long long)__shfl ((uint32_t)(nb >> 32), 0, WAVE) << 32) | __shfl ((uint32_t)nb, 0, WAVE);
   if (hit && rank >= room) {
     uint4 *a = record_address (E, nb + (rank - room));
@@ -278,15 +279,15 @@ emit_records_slow (const EmitCtx *Ep, WaveRec *W, uint32_t used, bool hit, uint3
       *a = rec;
   }
   if (lane == 0) {
-    const bool below = nb + REC_CHUNK <= E.capacity;
-    const bool above = nb >= E.capacity && nb - E.capacity + REC_CHUNK <= E.spill_slots;
+    const bool below = nb + chunk <= E.capacity;
+    const bool above = nb >= E.capacity && nb - E.capacity + chunk <= E.spill_slots;
     const uint64_t dst = below ? reinterpret_cast<uint64_t> (&E.records[nb]) : (above ? reinterpret_cast<uint64_t> (E.spill + (nb - E.capacity)) : 0ull);
     W->dst_lo = (uint32_t)dst;
     W->dst_hi = (uint32_t)(dst >> 32);
     W->base_lo = (uint32_t)nb;
     W->base_hi = (uint32_t)(nb >> 32);
-    W->limit = (below || above) ? REC_CHUNK : 0u;
-    if (E.chunk_prev) {
+    W->limit = (below || above) ? chunk : 0u;
+    if (E.chunk_prev) { /* (tiled scans: chunks of REC_CHUNK) */
       const uint32_t was = W->have ? (uint32_t)(base / REC_CHUNK) : NONE;
       if (below)
         E.chunk_prev[nb / REC_CHUNK] = was;

@@ -176,7 +176,9 @@ typedef struct {
   uint32_t records_direct; /* 1: the scan kernel writes the 16-byte records itself (kernel 5 on alphabets of at most 29
                               symbols; kernel 2); 0: it parks 8-byte items / hits that a second kernel turns into records */
   uint32_t variant;        /* kernel 5: 2 = scan_gram2_kernel (lane-local sieve on two bits per 4-gram: alphabets of up to
-                              26 symbols, no keywords of 1-3 symbols; ACM_GPU_GRAM2=0 selects the older form), else 0 */
+                              26 symbols + "other"; ACM_GPU_GRAM2=0 selects the older form); | 4: the keywords of 1-3 symbols
+                              have a pass of their own behind it (scan_short_kernel); | 8: that pass reads the keyword ids
+                              from HBM (more of them than LDS holds: about 29 K) */
 } ACMPlanInfo;
 
 /* Flattens `machine` and uploads the tables to `device`.  The plan is a snapshot: keywords

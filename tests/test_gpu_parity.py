@@ -1501,6 +1501,11 @@ def _random_case(rng, kind):
         kws = [rng.integers(97, 123, size=rng.integers(1, 12)).astype(np.uint8) for _ in range(int(rng.integers(10000, 12000)))]
         text = rng.integers(97, 123, size=int(rng.integers(50000, 300000))).astype(np.uint8)
         return kws, text, 1, {}
+    if kind == "shortlds":          # the same with few keywords of 1 and 2 symbols: scan_short_kernel has the keyword ids in LDS
+        kws = [rng.integers(97, 123, size=rng.integers(3, 12)).astype(np.uint8) for _ in range(int(rng.integers(10000, 12000)))]
+        kws += [rng.integers(97, 123, size=1).astype(np.uint8) for _ in range(2)] + [rng.integers(97, 123, size=2).astype(np.uint8) for _ in range(20)]
+        text = rng.integers(97, 123, size=int(rng.integers(50000, 300000))).astype(np.uint8)
+        return kws, text, 1, {}
     sym = 2 if kind.endswith("16") else 4
     dt = np.uint16 if sym == 2 else np.uint32
     V = int(rng.integers(5, 3000))
@@ -1509,7 +1514,45 @@ def _random_case(rng, kind):
     return kws, text, sym, ({"ACM_GPU_SPARSE": "walk"} if kind.startswith("walk") else {})
 
 
-@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "gramheads", "gram", "gramold", "gram26", "gram30", "gramsmall", "wide", "wideshort", "sticky", "short", "starts16", "starts32", "walk16", "walk32")
+@pytest.mark.parametrize("kind", ["gram", "gramold", "short", "shortlds"])
+@pytest.mark.parametrize("seg_log2", [0, 14])
+def test_record_chunks_of_4096_slots(torch_cuda, monkeypatch, kind, seg_log2):
+    """Scans of 64 MiB and more reserve their records 4,096 slots at a time instead of 1,024
+    (EmitCtx::rec_chunk; every wave adds to the same counter).  ACM_GPU_REC_CHUNK=4096 selects the
+    big chunks for a small text: whole scans, a buffer that is too small (the chunks past its
+    capacity go to the spill area and come back into the holes), shards, launch segments of 16 Ki
+    symbols (a wave carries its open chunk from one segment to the next), against the oracle."""
+    rng = np.random.default_rng(77 + seg_log2 + sum(map(ord, kind)))
+    kws, text, sym, env = _random_case(rng, kind)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("ACM_GPU_REC_CHUNK", "4096")
+    if seg_log2:
+        monkeypatch.setenv("ACM_GPU_SEGMENT_LOG2", str(seg_log2))
+    m, o = build_pair(kws, sym)
+    plan = m.plan(0)
+    assert plan.info.kernel == 5 and plan.info.records_direct == 1
+    want = o.scan(text)
+    assert want.size > 1000
+    dev = _dev(torch_cuda, text)
+    assert np.array_equal(plan.scan_sorted(dev), want)
+    rec, cnt = plan.scan(dev, capacity=want.size // 3)
+    assert int(cnt.item()) == want.size and rec.shape[0] == want.size // 3
+    assert np.array_equal(plan.scan_sorted(dev, capacity=want.size // 3), want)
+    rec, cnt = plan.scan(dev, capacity=want.size)      # exactly as many slots as records: every hole closed
+    assert int(cnt.item()) == want.size
+    got = np.frombuffer(rec[:want.size].cpu().numpy().tobytes(), dtype=acm.RECORD_DTYPE)
+    assert np.array_equal(np.sort(got, order=("end_pos", "length", "keyword_id")), np.sort(want, order=("end_pos", "length", "keyword_id")))
+    lo = text.size // 3
+    part = plan.scan_sorted(dev[lo - 16:], emit_from=16, pos_base=lo - 16) if lo >= 16 else None
+    if part is not None:    # (a shard that starts 16 symbols early: matches that end in it, global positions)
+        o_part = want[want["end_pos"] >= lo]
+        maxlen = max(len(k) for k in kws)
+        if maxlen <= 17:
+            assert np.array_equal(part, o_part)
+
+
+@pytest.mark.parametrize("kind,seed", [(k, s) for k in ("dense", "gramheads", "gram", "gramold", "gram26", "gram30", "gramsmall", "wide", "wideshort", "sticky", "short", "shortlds", "starts16", "starts32", "walk16", "walk32")
                                        for s in range(int(os.environ.get("ACM_SOAK_SEEDS", "3")))])   # ACM_SOAK_SEEDS=14: a soak run
 def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed):
     """Random dictionaries and texts through every kernel family; whole scans, count-only scans and
@@ -1530,13 +1573,14 @@ def test_randomized_dictionaries_and_shards(torch_cuda, monkeypatch, kind, seed)
             text[at:at + w.size] = w
     m, o = build_pair(kws, sym)
     plan = m.plan(0)
-    expect = {"dense": 1, "gramheads": 5, "gram": 5, "gramold": 5, "gram26": 5, "gram30": 5, "gramsmall": 5, "wide": 5, "wideshort": 5, "sticky": 1, "short": 5, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
-    if kind in ("gram", "gramold", "gram26", "gram30", "wide", "wideshort", "sticky", "short"):
+    expect = {"dense": 1, "gramheads": 5, "gram": 5, "gramold": 5, "gram26": 5, "gram30": 5, "gramsmall": 5, "wide": 5, "wideshort": 5, "sticky": 1, "short": 5, "shortlds": 5, "starts16": 4, "starts32": 4, "walk16": 3, "walk32": 3}[kind]
+    if kind in ("gram", "gramold", "gram26", "gram30", "wide", "wideshort", "sticky", "short", "shortlds"):
         assert plan.info.dense_rows > 32768, "the generator is meant to give more states than the LDS scheme takes"
     if kind in ("gram", "gramold", "gram26", "gram30"):
         assert plan.info.variant == (2 if kind in ("gram", "gram26") else 0), (kind, plan.info.variant)
-    if kind == "short":     # keywords of 1-3 symbols: a pass of their own (scan_short_kernel) behind the 4-gram kernel
-        assert plan.info.variant == 2 | 4, plan.info.variant
+    if kind in ("short", "shortlds"):   # keywords of 1-3 symbols: a pass of their own (scan_short_kernel) behind the 4-gram kernel;
+        # every letter and most pairs are keywords: 38 K ids, read from HBM (8) -- a few thousand: in LDS
+        assert plan.info.variant == 2 | 4 | (8 if kind == "short" else 0), plan.info.variant
     if kind == "dense":     # small dictionaries whose hot rows outgrow LDS go to the 4-gram kernel by themselves
         assert plan.info.kernel in (1, 5, 6), plan.info.kernel
     else:
