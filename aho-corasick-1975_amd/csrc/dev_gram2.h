@@ -1,5 +1,5 @@
 /* dev_gram2.h -- scan_gram2_kernel: the 4-gram kernel with a lane-local sieve (narrow alphabets whose
- * 2-bit table fits LDS, no keywords of 1-3 symbols).
+ * 2-bit table fits LDS; keywords of 1-3 symbols, if the dictionary has any, are scan_short_kernel's).
  * Device code of libac75_amd.so; included by dev_all.h inside its anonymous namespace.
  *
  * What it replaces (reference: the caller's loop acm_match -> acm_get_match, aho_corasick.c:434-482):
