@@ -176,12 +176,16 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
     const nt_u32x4 v = __builtin_nontemporal_load (reinterpret_cast<const nt_u32x4 *> (text16) + (blk < last_blk ? blk : last_blk));
     return make_uint4 (v.x, v.y, v.z, v.w);
   };
+  /* diagnostic build (make diag, tools/diag_gram2.py): cycles per wave by part of the group loop */
+  DIAG (const unsigned long long d_t0 = __builtin_readcyclecounter (); unsigned long long d_top = 0, d_sieve = 0, d_take = 0, d_cwait = 0, d_cons = 0, d_walk = 0, d_steps = 0;)
   auto walk_batch = [&] (uint32_t n_items) {
+    DIAG (const unsigned long long d_wk = __builtin_readcyclecounter ();)
     const unsigned long long r = walk_starts<uint8_t, COUNT_ONLY, 2> (Ks, Es, text, q2, qn2, n_items, hits, counted);
     qn2 = uniform ((uint32_t)(r >> 32));
     counted = (uint32_t)r;
     if (!COUNT_ONLY)
       rs = rec_state_load (hits); /* (the walk may have gone on to the next chunk) */
+    DIAG (d_walk += __builtin_readcyclecounter () - d_wk;)
   };
   /* Walk candidates between the entry and the walk queue: a candidate's first look is its depth-5
    * state's peek entry -- {its record, the symbol of its only edge} -- against the 6th symbol, whose
@@ -489,9 +493,13 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
         Ws[wib].s_late = stream_index (Ws[wib]);
       uint4 n3;
       uint32_t pass = 0, my = 0;
+      /* (diagnostic build: the wait for the group's text apart from the sieve) */
+      DIAG (const unsigned long long d_g0 = __builtin_readcyclecounter (); asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long d_g1 = __builtin_readcyclecounter (); d_top += d_g1 - d_g0;)
       const uint32_t total = sieve_group (c0, c1.x, c1.y, g0 + k, n3, pass, my);
+      DIAG (const unsigned long long d_g2 = __builtin_readcyclecounter (); d_sieve += d_g2 - d_g1; const unsigned long long d_in = d_cwait + d_cons + d_walk;)
       if (total)
         take_group (g0 + k, total, pass, my);
+      DIAG (d_take += (__builtin_readcyclecounter () - d_g2) - (d_cwait + d_cons + d_walk - d_in);)
       c0 = c1;
       c1 = c2;
       c2 = c3;
@@ -500,6 +508,17 @@ scan_gram2_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
   }
   if (!tiled)
     drain ();
+  DIAG (if (lane == 0 && wave_id < 8192) {
+    unsigned long long *o = g_acm_diag[wave_id];
+    o[0] = __builtin_readcyclecounter () - d_t0;
+    o[1] = d_top;
+    o[2] = d_sieve;
+    o[3] = d_take;
+    o[4] = d_cwait;
+    o[5] = d_cons;
+    o[6] = d_walk;
+    o[7] = d_steps;
+  })
   if (COUNT_ONLY) {
     const uint32_t incl = wave_incl_scan ((uint32_t)counted);
     const uint32_t total = __shfl (incl, WAVE - 1, WAVE);
