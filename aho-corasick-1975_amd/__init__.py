@@ -8,7 +8,7 @@ names, plus torch plumbing (device buffers, streams, torch.distributed) for the 
 There is no CPU scan path here: the bulk scan raises if the library or a GPU is missing.
 """
 from .binding import (  # noqa: F401
-    ACMError, Machine, Plan, Stream, MultiScan, FlatTables, RECORD_DTYPE, build_native, lib, library_path,
+    ACMError, Machine, Plan, Stream, MultiScan, Comm, FlatTables, RECORD_DTYPE, build_native, lib, library_path,
 )
 from . import synth  # noqa: F401
 from . import sharded  # noqa: F401

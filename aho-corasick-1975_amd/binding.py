@@ -81,7 +81,8 @@ EXPORTS = [
     "acm_gpu_stream_open", "acm_gpu_stream_feed", "acm_gpu_stream_finish", "acm_gpu_stream_close",
     "acm_gpu_multi_create", "acm_gpu_multi_destroy", "acm_gpu_multi_shard_bounds", "acm_gpu_multi_scan_host",
     "acm_gpu_multi_scan_device", "acm_set_symbol_bytes", "acm_scan_path", "acm_gpu_wire_bits", "acm_gpu_pack_records_device",
-    "acm_gpu_unpack_records_device",
+    "acm_gpu_unpack_records_device", "acm_gpu_comm_unique_id", "acm_gpu_comm_init_rank", "acm_gpu_comm_free", "acm_gpu_comm_create",
+    "acm_gpu_comm_destroy", "acm_gpu_comm_gather_records",
 ]
 
 
@@ -215,6 +216,18 @@ def lib():
     L.acm_gpu_multi_scan_host.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
     L.acm_gpu_multi_scan_device.restype = i32
     L.acm_gpu_multi_scan_device.argtypes = [vp, C.POINTER(vp), u64, vp, u64, C.POINTER(u64)]
+    L.acm_gpu_comm_unique_id.restype = i32
+    L.acm_gpu_comm_unique_id.argtypes = [vp]
+    L.acm_gpu_comm_init_rank.restype = i32
+    L.acm_gpu_comm_init_rank.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    L.acm_gpu_comm_free.restype = i32
+    L.acm_gpu_comm_free.argtypes = [vp]
+    L.acm_gpu_comm_create.restype = i32
+    L.acm_gpu_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.acm_gpu_comm_destroy.restype = None
+    L.acm_gpu_comm_destroy.argtypes = [vp]
+    L.acm_gpu_comm_gather_records.restype = i32
+    L.acm_gpu_comm_gather_records.argtypes = [vp, vp, vp, u64, u64, u64, vp, u64, C.POINTER(u64), C.POINTER(u64), vp]
     L.acm_gpu_plan_timing_read_all.restype = i32
     L.acm_gpu_plan_timing_read_all.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(u64)]
     L.acm_gpu_synth_text.restype = i32
@@ -725,6 +738,56 @@ class MultiScan:
         _check(lib().acm_gpu_multi_scan_device(self.h, ptrs, n_symbols, records.data_ptr(), records.shape[0], C.byref(found)),
                "acm_gpu_multi_scan_device")
         return int(found.value)
+
+
+class Comm:
+    """acm_gpu_comm_*: one process (or, in the tests, one thread) per rank; the ranks' ordered
+    records gathered on a root over RCCL through the C ABI (include/acm_gpu.h).  `unique_id()` on
+    one rank, its 128 bytes handed to the others, then Comm(id, rank, world) on every rank with its
+    device current."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().acm_gpu_comm_unique_id(buf), "acm_gpu_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, unique_id, rank, world, root=0):
+        self.rank, self.world, self.root = int(rank), int(world), int(root)
+        self.nccl = C.c_void_p()
+        self.h = C.c_void_p()
+        _check(lib().acm_gpu_comm_init_rank(C.create_string_buffer(bytes(unique_id), 128), self.rank, self.world, C.byref(self.nccl)),
+               "acm_gpu_comm_init_rank")
+        _check(lib().acm_gpu_comm_create(self.nccl, self.rank, self.world, self.root, C.byref(self.h)), "acm_gpu_comm_create")
+
+    def gather_records(self, plan, local, n_local, pos_lo, span, out=None, stream=None):
+        """local: int64 [*, 2] device tensor with this rank's n_local ordered records (positions in
+        [pos_lo, pos_lo + span)); out: int64 [cap, 2] device tensor on the root (None elsewhere).
+        Returns (records of all ranks, per-rank counts); raises ACMError(-4) on every rank when the
+        root's buffer is too small."""
+        total = C.c_uint64(0)
+        counts = (C.c_uint64 * self.world)()
+        rc = lib().acm_gpu_comm_gather_records(self.h, plan.h if plan is not None else None, local.data_ptr() if n_local else None, int(n_local),
+                                               int(pos_lo), int(span), out.data_ptr() if out is not None else None,
+                                               out.shape[0] if out is not None else 0, C.byref(total), counts, stream)
+        if rc == -4:
+            raise ACMError(rc, "acm_gpu_comm_gather_records: %d records, more than the root's buffer holds" % total.value)
+        _check(rc, "acm_gpu_comm_gather_records")
+        return int(total.value), [int(x) for x in counts]
+
+    def close(self):
+        if self.h:
+            lib().acm_gpu_comm_destroy(self.h)
+            self.h = None
+        if self.nccl:
+            lib().acm_gpu_comm_free(self.nccl)
+            self.nccl = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Stream:

@@ -212,6 +212,7 @@ acm_gpu_strerror (int code) {
   case ACM_GPU_E_INTERNAL: return "internal consistency check failed on the device";
   case ACM_GPU_E_FORMAT: return "not a valid flat-table blob";
   case ACM_GPU_E_IO: return "file could not be read or written";
+  case ACM_GPU_E_COMM: return "librccl.so could not be loaded or an RCCL call failed";
   default: return "unknown error";
   }
 }

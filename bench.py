@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="default line only: leave out the short runs of configs 3 and 5")
     ap.add_argument("--cpu-sample-mib", type=int, default=None)
     ap.add_argument("--no-multi-c-abi", action="store_true", help="leave out the e2e leg through acm_gpu_multi_scan_device (C ABI)")
+    ap.add_argument("--rccl-c-abi", action="store_true", help="N > 1: also time the e2e job through acm_gpu_comm_gather_records (C ABI over librccl.so); N = 1 runs it anyway")
+    ap.add_argument("--no-rccl-c-abi", action="store_true", help="leave that leg out at N = 1 too")
     return ap.parse_args()
 
 
@@ -256,6 +258,48 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
         if e2e_obj is not None and c_abi is not None:
             e2e_obj["c_abi"] = c_abi
 
+    # ---- and through the C ABI's RCCL gather (acm_gpu_comm_*: one process per GPU, the records sent to
+    # rank 0 by ncclSend / ncclRecv as 8-byte words) -- what a multi-process C caller runs.  At N = 1 by
+    # default (librccl.so itself: communicator, ncclAllGather of the counts); at N > 1 only with
+    # --rccl-c-abi: its send / receive path has run over the tests' loopback transport only.
+    if want_e2e and not rehearsal and e2e_obj is not None and (world == 1 or ctx.get("rccl_c_abi")) and not ctx.get("no_rccl_c_abi"):
+        rccl = None
+        try:
+            uid = [acm.Comm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            comm = acm.Comm(uid[0], rank, world, 0)
+            out = torch.empty((total_matches + 16, 2), dtype=torch.int64, device=cdev) if rank == 0 else None
+            r_steps = 1 if n_matches >= (1 << 24) else 3
+
+            def rccl_step():
+                _, _, order_tmp[0] = plan.scan_ordered(text, n_scan, emit_from=halo, pos_base=pos_base, records=records, count=count, tmp=order_tmp[0])
+                tot, _ = comm.gather_records(plan, records, int(count.item()), pos_base, n_scan, out)
+                torch.cuda.synchronize()
+                return tot
+
+            assert rccl_step() == total_matches
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(r_steps):
+                rccl_step()
+            barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            if rank == 0 and gathered is not None:
+                assert acm.synth.device_digest(out, total_matches) == acm.synth.device_digest(gathered, total_matches), "RCCL gather (C ABI): another record set"
+            rccl = {"ms_per_step": round(dt / r_steps * 1e3, 4), "value": round(total_bytes * r_steps / dt / 1e9, 3), "unit": "GB/s", "steps": r_steps,
+                    "what": "acm_gpu_scan_ordered_device on every rank + acm_gpu_comm_gather_records (C ABI over librccl.so: ncclAllGather of the counts, "
+                            "ncclSend / ncclRecv of 8-byte records to rank 0)"}
+            del out
+            comm.close()
+        except Exception as ex:       # the headline line must not depend on this leg
+            rccl = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        e2e_obj["c_abi_rccl"] = rccl
+
     res = None
     if rank == 0:
         if gathered is not None:
@@ -422,7 +466,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    ctx = dict(acm=acm, torch=torch, dist=dist, rank=rank, world=world, dev=dev, rehearsal=rehearsal, multi_c_abi=not args.no_multi_c_abi)
+    ctx = dict(acm=acm, torch=torch, dist=dist, rank=rank, world=world, dev=dev, rehearsal=rehearsal, multi_c_abi=not args.no_multi_c_abi,
+               rccl_c_abi=args.rccl_c_abi, no_rccl_c_abi=args.no_rccl_c_abi or args.no_multi_c_abi)
 
     res, keep = measure(ctx, args.config, cfg, args.steps, args.warmup, args.prewarm_ms, as_configured)
     out = None

@@ -50,7 +50,8 @@ enum {
   ACM_GPU_E_NOMEM = -6,
   ACM_GPU_E_INTERNAL = -7,   /* a device-side consistency check failed (never expected) */
   ACM_GPU_E_FORMAT = -8,     /* not a flat-table blob, wrong version, or its contents do not hold together */
-  ACM_GPU_E_IO = -9          /* a file could not be read or written */
+  ACM_GPU_E_IO = -9,         /* a file could not be read or written */
+  ACM_GPU_E_COMM = -10       /* librccl.so could not be loaded, or an RCCL call failed (message on stderr) */
 };
 const char *acm_gpu_strerror (int code);
 int acm_gpu_device_count (void);
@@ -355,6 +356,40 @@ int acm_gpu_multi_scan_host (ACMMulti *multi, const void *text, uint64_t n_symbo
  * Blocking. */
 int acm_gpu_multi_scan_device (ACMMulti *multi, const void *const *d_shard_text, uint64_t n_symbols,
                                ACMRecord *d_records, uint64_t capacity, uint64_t *n_found);
+
+/* ------------------------------------------------------------------ one process per GPU: the gather over RCCL
+ * The reference's model for parallel work is one shared read-only machine and one cursor per worker
+ * (README.md:364, aho_corasick.h:70); across PROCESSES that is one process per GPU, each with its
+ * own plan of the same dictionary, its shard of the text (acm_gpu_multi_shard_bounds' rule:
+ * contiguous ranges, an lmax - 1 halo) and its records from acm_gpu_scan_ordered_device.  The one
+ * exchange step -- BASELINE's "final RCCL gather of match records over xGMI" -- is this call: the
+ * counts travel by ncclAllGather, every rank's ordered records by ncclSend to `root`, which
+ * receives them (ncclRecv, one group) into their places in ONE buffer: shards own increasing
+ * position ranges, so rank order IS the canonical order.  Records travel as 8-byte words when the
+ * rank's plan says they fit (acm_gpu_wire_bits; `plan` may be NULL: 16 bytes) and are unpacked on
+ * the root.  xGMI is point-to-point: these are the direct peer-to-root transfers of SURVEY.md 8e.
+ *
+ * librccl.so is loaded when the first of these calls is made (dlopen; $ACM_GPU_COMM_LIB names
+ * another library with the same entry points -- the tests' loopback transport), so a single-GPU
+ * user of libac75_amd.so never loads it.  `nccl_comm` is an ncclComm_t (rccl.h), passed as void *:
+ * the caller's own, or one made here -- acm_gpu_comm_unique_id on one rank, its 128 bytes handed to
+ * the others by whatever the processes share (a file, a socket, MPI), acm_gpu_comm_init_rank on
+ * every rank with its device current.
+ * acm_gpu_comm_gather_records: collective over the communicator, every rank calls it with its own
+ * records (d_local[0 .. n_local), positions in [pos_lo, pos_lo + span)); on the root d_all takes
+ * `capacity` records.  *n_total (host, every rank) = the records of all ranks; more than the
+ * root's capacity: ACM_GPU_E_OVERFLOW on every rank, nothing sent.  The counts are exchanged
+ * before the call returns (one stream synchronisation); the transfers and the unpacking are
+ * queued on `stream`.  `counts` (host, `world` entries, may be NULL) = records per rank. */
+typedef struct ACMComm ACMComm;
+int acm_gpu_comm_unique_id (void *id_128_bytes);
+int acm_gpu_comm_init_rank (const void *id_128_bytes, int rank, int world, void **nccl_comm);
+int acm_gpu_comm_free (void *nccl_comm);
+int acm_gpu_comm_create (void *nccl_comm, int rank, int world, int root, ACMComm **out);
+void acm_gpu_comm_destroy (ACMComm *comm);
+int acm_gpu_comm_gather_records (ACMComm *comm, const ACMPlan *plan, const ACMRecord *d_local, uint64_t n_local,
+                                 uint64_t pos_lo, uint64_t span, ACMRecord *d_all, uint64_t capacity,
+                                 uint64_t *n_total, uint64_t *counts, void *stream);
 
 /* Waits for the plan's device and reports ACM_GPU_E_INTERNAL if a device-side consistency check
  * ever failed during its scans (never expected), else ACM_GPU_OK. */

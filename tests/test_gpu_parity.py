@@ -1514,6 +1514,56 @@ def _random_case(rng, kind):
     return kws, text, sym, ({"ACM_GPU_SPARSE": "walk"} if kind.startswith("walk") else {})
 
 
+def test_comm_gather_world_of_one_over_the_real_rccl(torch_cuda):
+    """acm_gpu_comm_*: the C ABI's gather of the ranks' records over RCCL, with librccl.so itself, at
+    the one world size a one-GPU box allows: the communicator is made through the library's own
+    entry points (unique id, init rank), the counts go through ncclAllGather, the root's own
+    records through the device copy; a too-small buffer is ACM_GPU_E_OVERFLOW with the total."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    kws = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) for _ in range(400)]
+    text = rng.integers(97, 123, size=1 << 20, dtype=np.uint8)
+    m, o = build_pair(kws, 1)
+    want = o.scan(text)
+    plan = m.plan(0)
+    rec, cnt, _ = plan.scan_ordered(_dev(torch, text), capacity=want.size + 8)
+    n = int(cnt.item())
+    assert n == want.size
+    comm = acm.Comm(acm.Comm.unique_id(), 0, 1)
+    out = torch.zeros((want.size, 2), dtype=torch.int64, device="cuda")
+    total, counts = comm.gather_records(plan, rec, n, 0, text.size, out)
+    torch.cuda.synchronize()
+    assert total == want.size and counts == [want.size]
+    assert np.array_equal(np.frombuffer(out.cpu().numpy().tobytes(), dtype=acm.RECORD_DTYPE), want)
+    with pytest.raises(acm.ACMError) as ei:
+        comm.gather_records(plan, rec, n, 0, text.size, out[:want.size - 1])
+    assert ei.value.code == -4
+    total, counts = comm.gather_records(None, rec, 0, 0, text.size, out)    # a rank with nothing to report
+    assert total == 0 and counts == [0]
+    comm.close()
+
+
+@pytest.mark.parametrize("world,root,wire", [(2, 0, 1), (3, 2, 1), (3, 0, 0), (5, 1, 1)])
+def test_comm_gather_ranks_as_threads_over_the_loopback_transport(torch_cuda, world, root, wire):
+    """The same gather at world sizes of 2, 3 and 5 on ONE GPU: the ranks are threads of a worker
+    process (tests/comm_loopback_worker.py), librccl.so is replaced by a loopback transport with the
+    same entry points (tests/helpers/loopback_comm.hip, ACM_GPU_COMM_LIB) -- who sends what to whom,
+    the offsets on the root, the 8-byte wire form and the 16-byte one, a root that is not rank 0, the
+    too-small root buffer reported to every rank: against the oracle's records of the whole text.
+    (RCCL's own send / receive between GPUs is what only a multi-GPU node can run.)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "helpers", "libloopback_comm.so")
+    src = os.path.join(here, "helpers", "loopback_comm.hip")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src, "-pthread"], check=True)
+    env = dict(os.environ, ACM_GPU_COMM_LIB=so)
+    r = subprocess.run([sys.executable, os.path.join(here, "comm_loopback_worker.py"), str(world), str(root), str(wire)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK world=%d" % world in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 @pytest.mark.parametrize("kind", ["gram", "gramold", "short", "shortlds"])
 @pytest.mark.parametrize("seg_log2", [0, 14])
 def test_record_chunks_of_4096_slots(torch_cuda, monkeypatch, kind, seg_log2):
