@@ -162,6 +162,7 @@ struct ACMPlan {
    * per wave and the spill area, one chunk of records per wave (64 MB on 256 CUs) */
   void *d_holes = nullptr, *d_spill = nullptr;
   uint32_t spill_chunk = 0; /* slots per chunk the spill area was sized for */
+  uint32_t holes_waves[2] = { 0, 0 }; /* waves of the widest launch of the scan at hand (4-gram pass, short-keyword pass): the holes to close */
   uint32_t direct_regions = 0;
   /* a tiled scan in progress (acm_gpu_scan_ordered_device -> scan_tiled): the 4-gram kernel writes
    * a TileEntry per tile from tiled_dir[tiled_base] on and links its chunks in tiled_prev */
@@ -1600,6 +1601,8 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t 
   uint32_t resume = first_segment ? 0u : 1u;
   if (holes && first_segment)
     HIP_TRY (hipMemsetAsync (holes, 0, (size_t)p->direct_regions * sizeof (RecHole), st));
+  if (first_segment || grid * wpb > p->holes_waves[0])
+    p->holes_waves[0] = grid * wpb;
   /* a tiled scan: a directory entry per tile, the chunks linked, the holes left alone (dev_tiles.h) */
   TileEntry *dir = (!COUNT_ONLY && direct) ? static_cast<TileEntry *> (p->tiled_dir) : nullptr;
   uint32_t dir_base = p->tiled_base;
@@ -1614,7 +1617,9 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t 
     if (direct && dir) {
       /* (nothing: tile_gather_kernel reads the records where they lie) */
     } else if (direct && last_segment) {
-      const uint32_t n_waves = p->direct_regions; /* (an earlier segment may have had more blocks than this one) */
+      /* (the waves of the scan's widest launch: an earlier segment may have had more blocks than this
+       * one; a short text has few -- every block of the kernel sorts all the descriptors it is given) */
+      const uint32_t n_waves = p->holes_waves[0];
       uint32_t npow = 64;
       while (npow < n_waves)
         npow <<= 1;
@@ -1655,13 +1660,15 @@ launch_short (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
   uint32_t resume = first_segment ? 0u : 1u;
   if (holes && first_segment)
     HIP_TRY (hipMemsetAsync (holes, 0, (size_t)short_regions * sizeof (RecHole), st));
+  if (first_segment || grid * wpb > p->holes_waves[1])
+    p->holes_waves[1] = grid * wpb;
   void *args[] = { &K, const_cast<EmitCtx *> (&E), &a, &a.text, &holes, &resume };
   HIP_TRY (hipLaunchKernel (short_kernel_ptr (COUNT_ONLY, p->short_ids_lds), dim3 (grid), dim3 (SPARSE_THREADS), args,
                             COUNT_ONLY ? p->short_lds_count_bytes : p->short_lds_bytes, st));
   if (stop)
     HIP_TRY (hipEventRecord (stop, st));
   if (!COUNT_ONLY && last_segment) {
-    const uint32_t n_waves = short_regions;
+    const uint32_t n_waves = p->holes_waves[1];
     uint32_t npow = 64;
     while (npow < n_waves)
       npow <<= 1;

@@ -305,7 +305,7 @@ emit_records_slow (const EmitCtx *Ep, WaveRec *W, uint32_t used, bool hit, uint3
  * the filled slots of [0, T) and there are C = T - H of them; those at C or beyond (in the
  * caller's buffer or, past its capacity, in the spill area) move into the holes below C, the k-th
  * hole slot taking the k-th such record, and the counter is rewound to C.
- * Every block sorts the holes by first slot in LDS (bitonic, <= 4,096 keys of start << HOLE_BITS | length),
+ * Every block sorts the holes by first slot in LDS (keys of start << HOLE_BITS | length, counted into place),
  * takes their prefix sums P, and handles the holes b, b + gridDim.x, ...: target = start_i + t is
  * hole slot number k = P[i] + t; its source is the filled slot of rank (C - M) + k (M = hole slots
  * below C), found by bisection on G[i] = start_i - P[i] = filled slots in front of hole i. */
@@ -321,7 +321,37 @@ close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t 
   const uint32_t tid = threadIdx.x;
   constexpr unsigned long long PAD = ~0ull << HOLE_BITS;
   constexpr uint32_t HOLE_MASK = (1u << HOLE_BITS) - 1;
-  for (uint32_t i = tid; i < npow; i += CLOSE_THREADS) {
+  /* The sort.  A bitonic network over 4,096 keys is 78 passes with a barrier each: 67 of the kernel's
+   * 107 us (an ablation build that sorted and moved nothing).  The keys are distinct and spread
+   * over a known range, so they are COUNTED into place instead: npow buckets by first slot (min
+   * and max by a reduction; a monotone map), an LDS atomic per key for its bucket's count and its
+   * arrival number, one prefix sum, every key written at its bucket's base + arrival number, and
+   * the few keys that share a bucket ranked among themselves -- five barriers.  The waves' last
+   * chunks cluster at the end of the range (a straggler's chunk far in front stretches it), which
+   * crowds buckets: past 64 keys in one the network below sorts instead. */
+  constexpr uint32_t PER_MAX = 8;
+  __shared__ unsigned long long s_lo[CLOSE_THREADS / WAVE], s_hi[CLOSE_THREADS / WAVE];
+  __shared__ uint32_t s_crowd;
+  unsigned long long kreg[PER_MAX];
+  unsigned long long klo = ~0ull, khi = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < PER_MAX; q++) {
+    const uint32_t i = tid + q * CLOSE_THREADS;
+    unsigned long long k = PAD;
+    if (i < n_waves && i < npow) {
+      const RecHole h = holes[i];
+      if (h.len)
+        k = (((unsigned long long)h.start_hi << 32 | h.start_lo) << HOLE_BITS) | h.len;
+    }
+    kreg[q] = k;
+    if (i < npow)
+      key[i] = k;
+    if (k != PAD) {
+      klo = (k >> HOLE_BITS) < klo ? (k >> HOLE_BITS) : klo;
+      khi = (k >> HOLE_BITS) > khi ? (k >> HOLE_BITS) : khi;
+    }
+  }
+  for (uint32_t i = tid + PER_MAX * CLOSE_THREADS; i < npow; i += CLOSE_THREADS) { /* (more holes than the counting takes: the network) */
     unsigned long long k = PAD;
     if (i < n_waves) {
       const RecHole h = holes[i];
@@ -330,10 +360,105 @@ close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t 
     }
     key[i] = k;
   }
-  if (tid == 0)
+  uint32_t *hist = P; /* [npow + 1] while the keys are being sorted (P is made afterwards) */
+  for (uint32_t i = tid; i <= npow; i += CLOSE_THREADS)
+    hist[i] = 0;
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const unsigned long long ol = __shfl_xor (klo, d, WAVE), oh = __shfl_xor (khi, d, WAVE);
+    klo = ol < klo ? ol : klo;
+    khi = oh > khi ? oh : khi;
+  }
+  if ((tid & (WAVE - 1)) == 0) {
+    s_lo[tid / WAVE] = klo;
+    s_hi[tid / WAVE] = khi;
+  }
+  if (tid == 0) {
     s_T = __hip_atomic_load (E.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_crowd = 0;
+  }
   __syncthreads ();
-  for (uint32_t k = 2; k <= npow; k <<= 1)
+  bool counted = npow <= CLOSE_THREADS * PER_MAX;
+  if (counted) {
+    for (int w = 0; w < CLOSE_THREADS / WAVE; w++) {
+      klo = s_lo[w] < klo ? s_lo[w] : klo;
+      khi = s_hi[w] > khi ? s_hi[w] : khi;
+    }
+    const double scale = khi >= klo ? (double)npow / (double)(khi - klo + 1) : 0.0;
+    uint32_t bkt[PER_MAX], slot[PER_MAX];
+#pragma unroll
+    for (uint32_t q = 0; q < PER_MAX; q++) {
+      bkt[q] = slot[q] = 0;
+      if (kreg[q] != PAD) {
+        const uint32_t b = (uint32_t)((double)((kreg[q] >> HOLE_BITS) - klo) * scale);
+        bkt[q] = b < npow - 1 ? b : npow - 1;
+        slot[q] = atomicAdd (&hist[bkt[q]], 1u);
+      }
+    }
+    __syncthreads ();
+    /* exclusive prefix of the counts in place (hist[npow] = the number of holes), the fullest bucket */
+    const uint32_t per = npow >= CLOSE_THREADS ? npow / CLOSE_THREADS : 1;
+    uint32_t run = 0, most = 0;
+    for (uint32_t q = 0; q < per; q++) {
+      const uint32_t i = tid * per + q;
+      if (i < npow) {
+        run += hist[i];
+        most = hist[i] > most ? hist[i] : most;
+      }
+    }
+    const uint32_t incl = wave_incl_scan (run);
+    if ((tid & (WAVE - 1)) == WAVE - 1)
+      s_part[tid / WAVE] = incl;
+    if (most > 64)
+      s_crowd = 1; /* (benign race: every writer writes 1) */
+    __syncthreads ();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w = 0; w < CLOSE_THREADS / WAVE; w++) {
+      before += w < tid / WAVE ? s_part[w] : 0u;
+      all += s_part[w];
+    }
+    counted = s_crowd == 0;
+    __syncthreads (); /* (s_part is used again below; hist is rewritten) */
+    if (counted) {
+      uint32_t acc = before + incl - run;
+      for (uint32_t q = 0; q < per; q++) {
+        const uint32_t i = tid * per + q;
+        if (i < npow) {
+          const uint32_t c = hist[i];
+          hist[i] = acc;
+          acc += c;
+        }
+      }
+      if (tid == 0)
+        hist[npow] = all;
+      __syncthreads ();
+#pragma unroll
+      for (uint32_t q = 0; q < PER_MAX; q++)
+        if (kreg[q] != PAD)
+          key[hist[bkt[q]] + slot[q]] = kreg[q];
+      for (uint32_t i = all + tid; i < npow; i += CLOSE_THREADS)
+        key[i] = PAD;
+      __syncthreads ();
+      uint32_t place[PER_MAX];
+#pragma unroll
+      for (uint32_t q = 0; q < PER_MAX; q++) {
+        place[q] = 0;
+        if (kreg[q] != PAD) {
+          const uint32_t base = hist[bkt[q]], end = hist[bkt[q] + 1];
+          uint32_t r = 0;
+          for (uint32_t x = base; x < end; x++)
+            r += key[x] < kreg[q] ? 1u : 0u;
+          place[q] = base + r;
+        }
+      }
+      __syncthreads ();
+#pragma unroll
+      for (uint32_t q = 0; q < PER_MAX; q++)
+        if (kreg[q] != PAD)
+          key[place[q]] = kreg[q];
+      __syncthreads ();
+    }
+  }
+  for (uint32_t k = 2; !counted && k <= npow; k <<= 1)
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
       for (uint32_t i = tid; i < npow; i += CLOSE_THREADS) {
         const uint32_t o = i ^ j;
@@ -409,6 +534,9 @@ close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t 
     if (!len || st >= C)
       continue;
     const uint32_t clipped = C - st < len ? (uint32_t)(C - st) : len;
+#if defined(ACM_CLOSE_ABLATE) && ACM_CLOSE_ABLATE == 1 /* experiment: the holes sorted and summed, nothing moved */
+    continue;
+#endif
     for (uint32_t t = tid; t < clipped; t += CLOSE_THREADS) {
       const unsigned long long r = first_rank + P[i] + t;
       /* holes in front of the filled slot of rank r: those with G = start - P <= r (G ascends) */
