@@ -1574,6 +1574,14 @@ gram_tiling (const ACMPlan *p, uint32_t n, uint32_t emit_from) {
   return t;
 }
 
+/* ACM_GPU_CLOSE_SORT=network: close_holes_kernel sorts its descriptors with the bitonic network whatever
+ * their spread (its fallback for crowded buckets; tests) */
+uint32_t
+close_network_only () {
+  const char *e = getenv ("ACM_GPU_CLOSE_SORT");
+  return e && strcmp (e, "network") == 0 ? 1u : 0u;
+}
+
 template <bool COUNT_ONLY>
 int
 launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t stop, bool first_segment, bool last_segment) {
@@ -1625,7 +1633,7 @@ launch_gram (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t 
         npow <<= 1;
       const uint32_t blocks = n_waves / 16 > 0 ? n_waves / 16 : 1; /* 16 holes per block */
       hipLaunchKernelGGL (close_holes_kernel, dim3 (blocks), dim3 (CLOSE_THREADS), npow * 16, st, E, static_cast<const RecHole *> (p->d_holes),
-                          n_waves, npow, reinterpret_cast<unsigned int *> (p->d_total + 1));
+                          n_waves, npow, reinterpret_cast<unsigned int *> (p->d_total + 1), close_network_only ());
       HIP_TRY (hipGetLastError ());
     } else if (!direct)
       launch_expand_hits (p, E, grid * wpb, st);
@@ -1674,7 +1682,7 @@ launch_short (ACMPlan *p, const EmitCtx &E, Launch a, hipStream_t st, hipEvent_t
       npow <<= 1;
     const uint32_t blocks = n_waves / 16 > 0 ? n_waves / 16 : 1;
     hipLaunchKernelGGL (close_holes_kernel, dim3 (blocks), dim3 (CLOSE_THREADS), npow * 16, st, E, holes, n_waves, npow,
-                        reinterpret_cast<unsigned int *> (p->d_total + 1));
+                        reinterpret_cast<unsigned int *> (p->d_total + 1), close_network_only ());
     HIP_TRY (hipGetLastError ());
   }
   return ACM_GPU_OK;

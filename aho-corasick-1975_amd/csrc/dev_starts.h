@@ -311,7 +311,7 @@ emit_records_slow (const EmitCtx *Ep, WaveRec *W, uint32_t used, bool hit, uint3
  * below C), found by bisection on G[i] = start_i - P[i] = filled slots in front of hole i. */
 constexpr int CLOSE_THREADS = 1024;
 __global__ __launch_bounds__ (CLOSE_THREADS) void
-close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t npow, unsigned int *ticket) {
+close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t npow, unsigned int *ticket, uint32_t network_only) {
   extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
   unsigned long long *key = reinterpret_cast<unsigned long long *> (smem); /* [npow] */
   uint32_t *P = reinterpret_cast<uint32_t *> (smem + (size_t)npow * 8);    /* [npow + 1] exclusive prefix of the lengths, then spare */
@@ -377,7 +377,7 @@ close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t 
     s_crowd = 0;
   }
   __syncthreads ();
-  bool counted = npow <= CLOSE_THREADS * PER_MAX;
+  bool counted = npow <= CLOSE_THREADS * PER_MAX && !network_only; /* (ACM_GPU_CLOSE_SORT=network: tests of the fallback) */
   if (counted) {
     for (int w = 0; w < CLOSE_THREADS / WAVE; w++) {
       klo = s_lo[w] < klo ? s_lo[w] : klo;

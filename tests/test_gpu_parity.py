@@ -1566,17 +1566,21 @@ def test_comm_gather_ranks_as_threads_over_the_loopback_transport(torch_cuda, wo
 
 @pytest.mark.parametrize("kind", ["gram", "gramold", "short", "shortlds"])
 @pytest.mark.parametrize("seg_log2", [0, 14])
-def test_record_chunks_of_4096_slots(torch_cuda, monkeypatch, kind, seg_log2):
+@pytest.mark.parametrize("close_sort", ["counted", "network"])
+def test_record_chunks_of_4096_slots(torch_cuda, monkeypatch, kind, seg_log2, close_sort):
     """Scans of 64 MiB and more reserve their records 4,096 slots at a time instead of 1,024
     (EmitCtx::rec_chunk; every wave adds to the same counter).  ACM_GPU_REC_CHUNK=4096 selects the
-    big chunks for a small text: whole scans, a buffer that is too small (the chunks past its
+    big chunks for a small text (and, with the small ones, close_holes_kernel's other way to sort
+    its descriptors): whole scans, a buffer that is too small (the chunks past its
     capacity go to the spill area and come back into the holes), shards, launch segments of 16 Ki
     symbols (a wave carries its open chunk from one segment to the next), against the oracle."""
     rng = np.random.default_rng(77 + seg_log2 + sum(map(ord, kind)))
     kws, text, sym, env = _random_case(rng, kind)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    monkeypatch.setenv("ACM_GPU_REC_CHUNK", "4096")
+    monkeypatch.setenv("ACM_GPU_REC_CHUNK", "4096" if close_sort == "counted" else "1024")
+    if close_sort == "network":     # close_holes_kernel's fallback for crowded buckets: the bitonic network
+        monkeypatch.setenv("ACM_GPU_CLOSE_SORT", "network")
     if seg_log2:
         monkeypatch.setenv("ACM_GPU_SEGMENT_LOG2", str(seg_log2))
     m, o = build_pair(kws, sym)
