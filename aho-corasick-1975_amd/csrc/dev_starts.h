@@ -931,6 +931,25 @@ scan_starts_kernel (StartsK K, EmitCtx E, Launch A, const unsigned char *__restr
       break;
     DIAG (d_tiles++;)
     const uint32_t g0 = tile * K.R;
+#ifndef ACM_STARTS16_DEEP /* (experiment: four and four for 2-byte symbols too) */
+#define ACM_STARTS16_DEEP 0
+#endif
+    if (sizeof (SYM) == 2 && !COUNT_ONLY && !ACM_STARTS16_DEEP) {
+      /* 2-byte symbols, with records: two pending starts per word, 40 registers of them -- two groups
+       * walked while two are in flight.  With four and four the kernel spilled 16 registers, the
+       * text it had just asked for among them: 1.49 -> 1.10 ms per Gi tokens (tools/exp_c5_16.py;
+       * count-only has registers to spare and keeps four: 1.00 against 1.05) */
+      uint4 c0 = load_group (g0), c1 = load_group (g0 + 1);
+      for (uint32_t k = 0; k < K.R; k += 2) {
+        const uint32_t g = g0 + k;
+        const uint4 n0 = load_group (g + 2), n1 = load_group (g + 3);
+        walk_group (c0, c1.x, g);
+        walk_group (c1, n0.x, g + 1);
+        c0 = n0;
+        c1 = n1;
+      }
+      continue;
+    }
     uint4 c0 = load_group (g0), c1 = load_group (g0 + 1), c2 = load_group (g0 + 2), c3 = load_group (g0 + 3);
     for (uint32_t k = 0; k < K.R; k += 4) {
       const uint32_t g = g0 + k;
