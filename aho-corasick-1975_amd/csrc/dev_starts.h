@@ -528,33 +528,84 @@ close_holes_kernel (EmitCtx E, const RecHole *holes, uint32_t n_waves, uint32_t 
   }
   __syncthreads ();
   const unsigned long long first_rank = C - s_M; /* rank (among the filled slots) of the first record at C or beyond */
-  for (uint32_t i = blockIdx.x; i < npow; i += gridDim.x) {
-    const unsigned long long st = key[i] >> HOLE_BITS;
-    const uint32_t len = (uint32_t)(key[i] & HOLE_MASK);
-    if (!len || st >= C)
-      continue;
-    const uint32_t clipped = C - st < len ? (uint32_t)(C - st) : len;
+  /* The move: hole slot number k (k-th slot of the holes below C, in slot order) takes the filled
+   * slot of rank first_rank + k.  The M slots are dealt out in equal stretches, one per wave of the
+   * grid (by hole -- a block per hole -- the blocks whose holes lie beyond C had nothing to do
+   * and the others 16 holes of up to 4,095 slots one after the other, a bisection per slot):
+   * a wave finds the hole of its first slot and the holes in front of its first source by
+   * bisection ONCE, then every lane walks on from where its last slot was (k and the rank only
+   * grow), four slots in flight per lane. */
+  const uint32_t M = s_M;
 #if defined(ACM_CLOSE_ABLATE) && ACM_CLOSE_ABLATE == 1 /* experiment: the holes sorted and summed, nothing moved */
-    continue;
+  if (M)
+    goto moved;
 #endif
-    for (uint32_t t = tid; t < clipped; t += CLOSE_THREADS) {
-      const unsigned long long r = first_rank + P[i] + t;
-      /* holes in front of the filled slot of rank r: those with G = start - P <= r (G ascends) */
+  {
+    const uint32_t lane = tid & (WAVE - 1);
+    const unsigned long long gw = (unsigned long long)blockIdx.x * (CLOSE_THREADS / WAVE) + tid / WAVE, GW = (unsigned long long)gridDim.x * (CLOSE_THREADS / WAVE);
+    const uint32_t k0 = (uint32_t)((unsigned long long)M * gw / GW), k1 = (uint32_t)((unsigned long long)M * (gw + 1) / GW);
+    auto real = [&] (uint32_t x) -> bool { return x < npow && (key[x] & HOLE_MASK) != 0; };
+    auto G = [&] (uint32_t x) -> unsigned long long { return (key[x] >> HOLE_BITS) - P[x]; };
+    if (k0 < k1) {
+      /* hh: the hole that holds slot k0 (the last one with P <= k0 among the holes that have slots) */
       uint32_t lo = 0, hi = npow;
       while (lo < hi) {
         const uint32_t mid = (lo + hi) / 2;
-        const unsigned long long g = (key[mid] >> HOLE_BITS) - P[mid];
-        if ((key[mid] & HOLE_MASK) != 0 ? g <= r : false) /* (the padding sorts last and is in front of nothing) */
+        if (real (mid) && P[mid] <= k0)
           lo = mid + 1;
         else
           hi = mid;
       }
-      const unsigned long long src = r + P[lo];
-      const uint4 *from = record_address (E, src);
-      if (from && st + t < E.capacity)
-        *reinterpret_cast<uint4 *> (&E.records[st + t]) = *from;
+      uint32_t hh = lo - 1; /* (k0 < M: hole 0 starts at P = 0 <= k0, so lo >= 1) */
+      /* gg: the holes in front of the filled slot of rank first_rank + k0: those with G = start - P <= rank (G ascends) */
+      const unsigned long long r0 = first_rank + k0;
+      lo = 0, hi = npow;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (real (mid) && G (mid) <= r0) /* (the padding sorts last and is in front of nothing) */
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      uint32_t gg = lo;
+      /* where slot k goes and where its record comes from (a lane without a slot reads something
+       * harmless: a load under a condition, or an array of the four in flight, went to scratch memory) */
+      auto prep = [&] (uint32_t k, unsigned long long &to, bool &ok) -> const uint4 * {
+        const uint4 *from = reinterpret_cast<const uint4 *> (holes);
+        ok = false;
+        to = 0;
+        if (k < k1) {
+          while (real (hh + 1) && P[hh + 1] <= k)
+            hh++;
+          to = (key[hh] >> HOLE_BITS) + (k - P[hh]);
+          const unsigned long long r = first_rank + k;
+          while (real (gg) && G (gg) <= r)
+            gg++;
+          const uint4 *at = record_address (E, r + P[gg]);
+          ok = at != nullptr && to < E.capacity;
+          from = ok ? at : from;
+        }
+        return from;
+      };
+      for (uint32_t base = k0 + lane; base < k1; base += WAVE * 4) {
+        unsigned long long t0, t1, t2, t3;
+        bool o0, o1, o2, o3;
+        const uint4 *f0 = prep (base, t0, o0), *f1 = prep (base + WAVE, t1, o1), *f2 = prep (base + 2 * WAVE, t2, o2), *f3 = prep (base + 3 * WAVE, t3, o3);
+        const uint4 v0 = *f0, v1 = *f1, v2 = *f2, v3 = *f3;
+        if (o0)
+          *reinterpret_cast<uint4 *> (&E.records[t0]) = v0;
+        if (o1)
+          *reinterpret_cast<uint4 *> (&E.records[t1]) = v1;
+        if (o2)
+          *reinterpret_cast<uint4 *> (&E.records[t2]) = v2;
+        if (o3)
+          *reinterpret_cast<uint4 *> (&E.records[t3]) = v3;
+      }
     }
   }
+#if defined(ACM_CLOSE_ABLATE) && ACM_CLOSE_ABLATE == 1
+moved:
+#endif
   /* the block that finishes last rewinds the counter: every block has read T by then */
   __syncthreads ();
   if (tid == 0) {
