@@ -250,7 +250,15 @@ scan_dense_kernel (DenseK K, EmitCtx E, Launch A, const ENTRY *__restrict__ gden
   uint4 d[NB][S], post[S];
   auto load_block = [&] (uint32_t p0, int k, int q) -> uint4 {
     const uint32_t off = p0 + q * (WAVE * C) + 16 * k;
+#ifdef ACM_DENSE_NT /* experiment: the text as a stream that should not stay in the caches -- 0.269 -> 0.493 ms per GiB:
+                     * a lane owns 64 contiguous bytes, so each of a wave's four loads touches every 64-byte
+                     * sector of its 4 KiB and three of the four find it in L1 / L2 only if it may stay there */
+    typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+    const u32x4 v = __builtin_nontemporal_load (reinterpret_cast<const u32x4 *> (text + (off < last_block ? off : last_block)));
+    return make_uint4 (v.x, v.y, v.z, v.w);
+#else
     return *reinterpret_cast<const uint4 *> (text + (off < last_block ? off : last_block));
+#endif
   };
   {
     const uint32_t p0 = cur * TILE + lane * C;
