@@ -649,7 +649,8 @@ class Plan:
         _check(lib().acm_gpu_plan_status(self.h), "acm_gpu_plan_status")
 
     def timing(self, enable=True):
-        _check(lib().acm_gpu_plan_timing(self.h, 1 if enable else 0), "acm_gpu_plan_timing")
+        """True / 1: HIP events around every launch's scan kernel; N > 1: around every N-th launch's; False: off."""
+        _check(lib().acm_gpu_plan_timing(self.h, int(enable)), "acm_gpu_plan_timing")
 
     def timing_read(self):
         ms, n = C.c_double(0), C.c_uint64(0)

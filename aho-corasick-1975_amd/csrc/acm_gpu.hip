@@ -191,6 +191,7 @@ struct ACMPlan {
   int cu_count = 0;
   /* timing */
   bool timing = false;
+  uint32_t timing_every = 1, timing_seq = 0; /* events around every timing_every-th launch (acm_gpu_plan_timing) */
   struct LaunchEvents {
     hipEvent_t start, scan_done, all_done; /* around the scan kernel; after what follows it (expansion / hole closing) */
   };
@@ -1395,6 +1396,8 @@ acm_gpu_plan_timing (ACMPlan *plan, int enable) {
   if (!plan)
     return ACM_GPU_E_ARG;
   plan->timing = enable != 0;
+  plan->timing_every = enable > 1 ? (uint32_t)enable : 1u;
+  plan->timing_seq = 0;
   plan->events_used = 0;
   plan->timing_ms = 0;
   plan->timing_all_ms = 0;
@@ -1437,7 +1440,7 @@ int
 timing_begin (ACMPlan *p, hipStream_t st, hipEvent_t *stop, hipEvent_t *stop_all) {
   *stop = nullptr;
   *stop_all = nullptr;
-  if (!p->timing)
+  if (!p->timing || p->timing_seq++ % p->timing_every != 0)
     return ACM_GPU_OK;
   if (p->events_used == p->events.size ()) {
     if (p->events.size () >= 4096) { /* fold what is recorded so far */

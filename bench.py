@@ -169,8 +169,21 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
             prewarm_steps += 8
     for _ in range(warmup):
         step()
+    # launches of the scan kernel per step (a 16 GiB step is 8 launches of 2^31 symbols): one untimed step with events
+    plan.timing(1)
+    step()
+    launches_per_step = max(plan.timing_read_all()[2], 1)
+    plan.timing(False)
+    # The kernel's duration is measured live, by HIP events on the launch stream inside the timed region --
+    # around a SAMPLE of its launches: the three events of a launch (start, end of the scan kernel, end of
+    # the kernel behind it) cost about 10 us on the stream (tools/exp_timing_overhead.py: a step of config
+    # 2 takes 282 us without them, 292 with), which is not the job's time.  About five launches are
+    # sampled, an odd period so that they fall on different launches of a step.
+    timing_every = max(1, launches_per_step * steps // 5)
+    if timing_every > 1 and timing_every % 2 == 0:
+        timing_every += 1
     barrier()
-    plan.timing(True)
+    plan.timing(timing_every)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -314,7 +327,6 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
                 assert acm.synth.device_digest(g, g.shape[0]) == (full_count, full_digest), "ordered records differ from the scan's record set"
             del g
         # a step is one launch of the scan kernel per segment of 2^31 symbols (16 GiB: 8 launches)
-        launches_per_step = max(kern_launches // max(steps, 1), 1)
         kern_avg_ms = kern_ms / max(kern_launches, 1)
         follow_avg_ms = (all_ms - kern_ms) / max(kern_launches, 1)
         # sym bytes read per symbol + 16 bytes written per record -- of which the timed
@@ -366,6 +378,8 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kname, "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": kern_launches,
                 "launches_per_step": launches_per_step,
+                "events": "HIP events on the launch stream around every %s launch of the timed region (%d of its %d launches)" % (
+                    "" if timing_every == 1 else "%d-th" % timing_every, kern_launches, launches_per_step * steps),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "algorithmic_bytes": "%d B per symbol read + %d B per record written by this kernel (%s)" % (
                     sym, int(rec_bytes_scan), "the 16-byte records themselves" if direct else
