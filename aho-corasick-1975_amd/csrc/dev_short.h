@@ -209,8 +209,9 @@ scan_short_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
       const uint32_t b = (w[j / 4] >> (8 * (j % 4))) & 0xFFu;
       c[j] = min (b - K.lo, K.span);
     }
-    /* symbols past the end of the segment count as outside the alphabet (only the last groups) */
-    if (pos0 + 18 > A.n) {
+    /* symbols past the end of the segment count as outside the alphabet (only the last groups: asked of
+     * the group, in a scalar register -- asked of the lane it became 18 compares and selects per group) */
+    if (__builtin_expect (uniform (g * GROUP + GROUP + 18) > A.n, 0)) {
 #pragma unroll
       for (int j = 0; j < 18; j++)
         if (pos0 + j >= A.n)
@@ -233,8 +234,8 @@ scan_short_kernel (GramK K, EmitCtx E, Launch A, const unsigned char *__restrict
       if (h == 0)
         __builtin_amdgcn_sched_barrier (0);
     }
-    if (pos0 + 16 > A.n) /* (a position beyond the segment is no position) */
-      pass &= pos0 < A.n ? (1u << (A.n - pos0)) - 1u : 0u;
+    if (__builtin_expect (uniform (g * GROUP + GROUP) > A.n, 0)) /* (a position beyond the segment is no position) */
+      pass &= pos0 + 16 <= A.n ? ~0u : (pos0 < A.n ? (1u << (A.n - pos0)) - 1u : 0u);
     const uint32_t cnt = __popc (pass);
     const uint32_t incl = wave_incl_scan_dpp (cnt);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane ((int)incl, WAVE - 1);
