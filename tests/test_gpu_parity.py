@@ -1514,6 +1514,31 @@ def _random_case(rng, kind):
     return kws, text, sym, ({"ACM_GPU_SPARSE": "walk"} if kind.startswith("walk") else {})
 
 
+def test_plan_timing_samples_every_nth_launch(torch_cuda):
+    """acm_gpu_plan_timing (plan, N): HIP events around every N-th launch only (what bench.py uses: the
+    events of a launch cost about 10 us on the stream).  Seven scans at N = 3: launches 0, 3 and 6."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    kws = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) for _ in range(300)]
+    text = rng.integers(97, 123, size=1 << 20, dtype=np.uint8)
+    m, o = build_pair(kws, 1)
+    plan = m.plan(0)
+    dev = _dev(torch, text)
+    want = o.count(text)
+    for every, scans, sampled in ((1, 4, 4), (3, 7, 3), (5, 5, 1), (2, 1, 1)):
+        plan.timing(every)
+        for _ in range(scans):
+            rec, cnt = plan.scan(dev, capacity=want + 8)
+        torch.cuda.synchronize()
+        scan_ms, all_ms, launches = plan.timing_read_all()
+        plan.timing(False)
+        assert launches == sampled, (every, scans, launches)
+        assert 0 < scan_ms <= all_ms and int(cnt.item()) == want
+    plan.timing(False)
+    plan.scan(dev, capacity=want + 8)
+    assert plan.timing_read_all()[2] == 0
+
+
 def test_comm_gather_world_of_one_over_the_real_rccl(torch_cuda):
     """acm_gpu_comm_*: the C ABI's gather of the ranks' records over RCCL, with librccl.so itself, at
     the one world size a one-GPU box allows: the communicator is made through the library's own
