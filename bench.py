@@ -179,7 +179,8 @@ def measure(ctx, config, cfg, steps, warmup, prewarm_ms, as_configured, want_e2e
     # the kernel behind it) cost about 10 us on the stream (tools/exp_timing_overhead.py: a step of config
     # 2 takes 282 us without them, 292 with), which is not the job's time.  About five launches are
     # sampled, an odd period so that they fall on different launches of a step.
-    timing_every = max(1, launches_per_step * steps // 5)
+    total_launches = launches_per_step * steps
+    timing_every = max(1, total_launches // (5 if total_launches >= 20 else 3 if total_launches >= 6 else 2))
     if timing_every > 1 and timing_every % 2 == 0:
         timing_every += 1
     barrier()
